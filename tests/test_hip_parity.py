@@ -1,0 +1,212 @@
+"""Parity of the HIP engine (through the C ABI) with the golden fixtures the Python reference
+produced and with the CPU oracle on seeded inputs.  Bit-exact everywhere: the path is integer
+work.  Needs a real MI355X: run with  python -m pytest tests -m gpu."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as op
+import tetris_rl_amd as trl
+
+pytestmark = pytest.mark.gpu
+
+SEED = 20260630
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def _state_for_case(rows, piece, held, q0):
+    st = np.zeros(320, dtype=np.uint8)
+    st[0:80] = np.asarray(rows, dtype="<u2").view(np.uint8)
+    st[112] = q0 & 15
+    st[132:134] = np.array([-1], dtype="<i2").view(np.uint8)
+    st[137], st[138] = piece, held
+    st[139] = 1 if q0 != 7 else 0
+    st[144 + 132:144 + 134] = np.array([-1], dtype="<i2").view(np.uint8)
+    st[144 + 137] = st[144 + 138] = 7
+    st[314] = 1
+    return st
+
+
+def _lists(counts, moves):
+    return [moves[i, :counts[i]] for i in range(counts.shape[0])]
+
+
+def test_attack_formulas_exhaustive(golden_dir):
+    """integer restatement of Stats.get_attack on the device == the reference's floats,
+    all 604 800 combinations (stats.py:45-157)."""
+    t = np.ascontiguousarray(_load(golden_dir, "attack.npz")["table"])
+    L = trl.load_library()
+    rows = np.ascontiguousarray(t[:, :8])
+    out = np.zeros((rows.shape[0], 4), dtype=np.int16)
+    L.trl_debug_attack_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    assert L.trl_debug_attack_table(rows.ctypes.data, rows.shape[0], out.ctypes.data) == 0
+    bad = np.nonzero((out != t[:, 8:12]).any(axis=1))[0]
+    assert bad.size == 0, "first mismatch: in=%s ref=%s hip=%s" % (t[bad[0], :8], t[bad[0], 8:], out[bad[0]])
+
+
+def test_env_traces_lockstep(golden_dir):
+    """80 reference games replayed in lockstep: at every ply the legal list (argwhere order)
+    and the complete two-player state equal the reference's."""
+    d = _load(golden_dir, "env_traces.npz")
+    meta = d["meta"]
+    counts_all = d["legal_counts"]
+    offs = np.concatenate([[0], np.cumsum(counts_all)])
+    n = meta.shape[0]
+    moves_off = np.concatenate([[0], np.cumsum(meta[:, 3])])
+    e = trl.Engine(n, ruleset="s2", seed=int(d["seed"]))
+    e.set_state(d["states"][meta[:, 4]])         # ply-0 states (both rulesets: the state carries it)
+    max_plies = int(meta[:, 3].max())
+    checked = 0
+    for k in range(max_plies + 1):
+        st = e.get_state()
+        cnt, mv = e.legal_moves()
+        step = np.full(n, trl.MOVE_NONE, dtype=np.uint16)
+        for g in range(n):
+            npl, s_off, l_off = int(meta[g, 3]), int(meta[g, 4]), int(meta[g, 5])
+            if k > npl:
+                continue
+            a, b = st[g].copy(), d["states"][s_off + k].copy()
+            a[304:308] = 0; b[304:308] = 0       # pol_ctr: moves are replayed, not drawn
+            assert np.array_equal(a, b), "state mismatch game %d ply %d" % (g, k)
+            ref = d["legal_flat"][offs[l_off + k]:offs[l_off + k + 1]]
+            assert np.array_equal(mv[g, :cnt[g]], ref), "legal list mismatch game %d ply %d" % (g, k)
+            checked += 1
+            if k < npl:
+                step[g] = d["moves"][moves_off[g] + k]
+        e.step(step, add_bag=True, check_legal=True)
+    assert checked == d["states"].shape[0]
+    assert not (e.get_state()[:, 313] & 3).any(), "overflow / bad-move flag set"
+
+
+def test_step_cases(golden_dir):
+    """8092 (state, move) -> state cases of crafted / cave / sampled positions in one batch."""
+    d = _load(golden_dir, "step_cases.npz")
+    sin, cs, cm, sout = d["states_in"], d["case_state"], d["case_move"], d["states_out"]
+    e = trl.Engine(cm.shape[0], ruleset="s2", seed=int(d["seed"]))
+    e.set_state(sin[cs])
+    cnt, mv = e.legal_moves()
+    # the legal list of every input state is exactly the set of moves the reference enumerated
+    for sid in range(sin.shape[0]):
+        idx = np.nonzero(cs == sid)[0]
+        if idx.size:
+            assert np.array_equal(mv[idx[0], :cnt[idx[0]]], cm[idx]), "legal list of state %d" % sid
+    e.step(cm, add_bag=True, check_legal=True)
+    got = e.get_state()
+    bad = np.nonzero((got != sout).any(axis=1))[0]
+    assert bad.size == 0, "case %d (state %d move %d) differs at bytes %s" % (
+        bad[0], cs[bad[0]], cm[bad[0]], np.nonzero(got[bad[0]] != sout[bad[0]])[0][:16])
+    # states without any legal move (topped-out crafted boards) must enumerate nothing
+    empty = [sid for sid in range(sin.shape[0]) if not (cs == sid).any()]
+    if empty:
+        e2 = trl.Engine(len(empty), seed=int(d["seed"]))
+        e2.set_state(sin[empty])
+        c2, _ = e2.legal_moves()
+        assert not c2.any()
+
+
+def test_movegen_cases(golden_dir):
+    """reference test boards (util.py:34-37) x 7 pieces x {no hold, hold == piece}, the empty
+    board (tests.py:23-32: O -> 9 placements) and 592 sampled positions."""
+    d = _load(golden_dir, "movegen.npz")
+    n = d["rows"].shape[0]
+    states = np.stack([_state_for_case(d["rows"][i], int(d["piece"][i]), int(d["held"][i]), int(d["q0"][i]))
+                       for i in range(n)])
+    e = trl.Engine(n, seed=SEED)
+    e.set_state(states)
+    cnt, mv = e.legal_moves()
+    cc = np.concatenate([[0], np.cumsum(d["conv_counts"])])
+    for i in range(n):
+        assert np.array_equal(mv[i, :cnt[i]], d["conv_flat"][cc[i]:cc[i + 1]]), "case %d" % i
+    # known answer of the reference's own test
+    st = _state_for_case(np.zeros(40, dtype=np.uint16), 2, 2, 0)
+    e1 = trl.Engine(1, seed=SEED)
+    e1.set_state(st[None])
+    c1, _ = e1.legal_moves()
+    assert int(c1[0]) == 9
+
+
+def test_uniform_games_from_seed_only(golden_dir):
+    """the reference's uniform-policy games are reproduced by the fused rollout kernel from
+    (seed, stream) alone -- bags, garbage columns and move choices all come from the RNG."""
+    d = _load(golden_dir, "env_traces.npz")
+    meta = d["meta"]
+    for ruleset, name in ((1, "s1"), (2, "s2")):
+        games = [g for g in range(meta.shape[0]) if meta[g, 2] == 0 and meta[g, 0] == ruleset]
+        streams = np.array([meta[g, 1] for g in games], dtype=np.uint32)
+        e = trl.Engine(len(games), ruleset=name, seed=int(d["seed"]))
+        e.reset(streams)
+        shortest = int(min(meta[g, 3] for g in games))
+        for k in range(1, shortest):
+            e.rollout_random(1)
+            st = e.get_state()
+            for j, g in enumerate(games):
+                assert np.array_equal(st[j], d["states"][meta[g, 4] + k]), "game %d ply %d" % (g, k)
+
+
+@pytest.mark.parametrize("ruleset", ["s1", "s2"])
+def test_rollout_matches_oracle(ruleset):
+    """C2-shaped workload, seeded: 1024 games x 120 plies with auto-reset; final states, step
+    count and the legal lists of the final positions equal the CPU oracle's."""
+    n, plies = 1024, 120
+    e = trl.Engine(n, ruleset=ruleset, seed=SEED)
+    e.reset()
+    ob = op.OracleBatch(n, ruleset=trl.engine.RULESETS[ruleset], seed=SEED)
+    assert np.array_equal(e.get_state(), ob.export())
+    steps = e.rollout_random(plies)
+    osteps = ob.rollout_random(plies)
+    assert steps == osteps
+    got, want = e.get_state(), ob.export()
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert bad.size == 0, "%d games differ, first %d" % (bad.size, bad[0])
+    assert (got[:, 308:312].view("<u4") > 0).any(), "no game was auto-reset: the test is too short"
+    cnt, mv = e.legal_moves()
+    for g in range(0, n, 7):
+        assert np.array_equal(mv[g, :cnt[g]], ob.legal_moves(g))
+
+
+def test_rollout_full_size_properties():
+    """BASELINE config C2 (4096 games) at full length through size-independent properties:
+    determinism, split invariance (1000 plies == 4 x 250), no cap overflow, board/stat
+    invariants; games 0..63 are also checked against the oracle over all 1000 plies."""
+    n, plies = 4096, 1000
+    a = trl.Engine(n, seed=SEED); a.reset()
+    b = trl.Engine(n, seed=SEED); b.reset()
+    sa = a.rollout_random(plies)
+    sb = sum(b.rollout_random(250) for _ in range(4))
+    A, B = a.get_state(), b.get_state()
+    assert sa == sb and np.array_equal(A, B)
+    assert not (A[:, 313] & 3).any(), "overflow / bad-move flag"
+    rows = A[:, :288].reshape(n, 2, 144)[:, :, :80].copy().view("<u2")
+    assert (rows < 1024).all()
+    assert (rows != 1023).all(), "a full row survived a lock"
+    ply = A[:, 300:304].copy().view("<u4")[:, 0]
+    pieces = A[:, :288].reshape(n, 2, 144)[:, :, 120:124].copy().view("<i4")[:, :, 0]
+    assert np.array_equal(pieces.sum(axis=1).astype(np.uint32), ply)
+    assert sa > 0.95 * n * plies
+    ob = op.OracleBatch(64, ruleset=2, seed=SEED)
+    ob.rollout_random(plies)
+    assert np.array_equal(A[:64], ob.export())
+
+
+def test_bad_move_is_rejected():
+    e = trl.Engine(2, seed=SEED)
+    e.reset()
+    before = e.get_state()
+    e.step(np.array([trl.encode_move(26, 0, 0), trl.MOVE_NONE], dtype=np.uint16), check_legal=True)
+    after = e.get_state()
+    assert after[0, 313] & 2 and np.array_equal(after[1], before[1])
+    after[0, 313] &= ~np.uint8(2)
+    assert np.array_equal(after[0], before[0])
+
+
+def test_call_order_errors():
+    e = trl.Engine(2, seed=SEED)
+    with pytest.raises(trl.EngineError):
+        e.legal_moves()
+    with pytest.raises(trl.EngineError):
+        e.rollout_random(1)

@@ -1,0 +1,11 @@
+"""MI355X-native self-play rollout engine for turn-based TETR.IO (HIP, gfx950).
+
+Import name: ``tetris_rl_amd`` (the directory name carries the reference's hyphenated
+repository name, so the repo root ships ``tetris_rl_amd.py`` which loads this package).
+"""
+from .engine import Engine, EngineError, encode_move, decode_move, load_library, STATE_BYTES, MAX_LEGAL, MOVE_NONE  # noqa: F401
+from . import build as _build_mod
+
+
+def build(force=False, verbose=False):
+    return _build_mod.build(force=force, verbose=verbose)

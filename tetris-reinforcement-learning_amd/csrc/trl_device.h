@@ -1,0 +1,490 @@
+// trl_device.h -- device functions of the env-step path (gfx950, wave64).
+//
+// Mapping to the hardware
+//   * one wavefront per (game, piece type) runs the legal-placement search of
+//     move_generation.py:325-488 on 14-bit row masks held in LDS: the search itself is an
+//     ordered FIFO walk (the T-spin sub-plane of a placement depends on the order in which
+//     kicks reach it, move_generation.py:671-677), so the FIFO is drained in order while the
+//     work inside one item is spread over the lanes -- queue items are classified 64 at a
+//     time, a flooded row's (edge column x rotation direction) kick probes run one per lane,
+//     and pushes are appended with ballot + popcount so the queue keeps the reference order;
+//   * the board is staged once per step in LDS as 40 ten-bit rows;
+//   * one lane applies the chosen placement (lock, line clear, attack, garbage, spawn).
+//
+// Every function cites the reference lines it re-implements; the arithmetic is integer-only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/tetris_engine.h"
+#include "trl_tables.h"
+
+namespace trl {
+
+constexpr int MAP_W = 14;          // validity-map width  (COLS + 4), x in [-2, 11]
+constexpr int MAP_H = 44;          // validity-map height (ROWS + 4), y in [-2, 41]
+constexpr int QCAP  = 1024;        // FIFO capacity per search (observed max 511 in random play)
+constexpr int SPAWN_Y = TRL_ROWS - TRL_SPAWN_ROW;   // 17
+
+// LDS scratch of one wavefront's search
+struct MgScratch {
+    uint16_t valid[4][MAP_H];      // valid[r][ym] bit xm: piece (rotation r) at origin (xm-2, ym-2) fits
+    uint16_t visited[4][MAP_H];
+    uint16_t present[4][MAP_H];    // unflagged placements
+    uint16_t flagp[4][MAP_H];      // placements reached by a rotation (rotation_just_occurred)
+    uint16_t ulp[4][MAP_H];        // ... whose last writer used the last kick of its list
+    uint16_t queue[QCAP];          // mx:4 | my:6 | rot:2 | flag:1 | last_kick:1
+};
+
+// ---- wave helpers -------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync() {
+    // LDS accesses of one wavefront execute in order; this only pins the compiler.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int lane_rank(uint64_t mask, int lane) {
+    return __popcll(mask & ((1ull << lane) - 1ull));
+}
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// ---- rng (include/tetris_engine.h) ----------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ uint32_t rng_below(uint64_t seed, uint32_t stream, uint32_t purpose, uint64_t ctr, uint32_t n) {
+    uint64_t k = mix64(seed ^ ((uint64_t)stream * 0xD1342543DE82EF95ull));
+    uint32_t u = (uint32_t)(mix64(k ^ ((uint64_t)purpose << 56) ^ ctr) >> 32);
+    return (uint32_t)(((uint64_t)u * n) >> 32);
+}
+
+// ---- board primitives on bit rows -----------------------------------------------------------
+// Board.is_valid_position over the 4 minos of a pose (board.py:23-30, piece.py:50-55)
+__device__ __forceinline__ bool pose_fits(const uint16_t *rows, int type, int x, int y, int rot) {
+    uint32_t m = C_MINO[type * 4 + rot];
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int col = x + (int)((m >> (4 * i)) & 3), row = y + (int)((m >> (4 * i + 2)) & 3);
+        bool in = (unsigned)row < (unsigned)TRL_ROWS && (unsigned)col < (unsigned)TRL_COLS;
+        ok = ok && in && !((rows[in ? row : 0] >> (in ? col : 0)) & 1);
+    }
+    return ok;
+}
+__device__ __forceinline__ bool cell_free(const uint16_t *rows, int col, int row) {
+    bool in = (unsigned)row < (unsigned)TRL_ROWS && (unsigned)col < (unsigned)TRL_COLS;
+    return in && !((rows[in ? row : 0] >> (in ? col : 0)) & 1);
+}
+__device__ __forceinline__ int spawn_x(int type) { return 3 + (type == PO ? 1 : 0); }   // piece.py:17-21
+
+// one row of the validity map (move_generation.py:490-528): AND over the minos of the
+// shifted free-cell rows
+__device__ __forceinline__ uint32_t valid_row(const uint16_t *rows, int type, int rot, int ym) {
+    uint32_t m = C_MINO[type * 4 + rot];
+    uint32_t v = 0x3FFFu;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int cx = (int)((m >> (4 * i)) & 3), cy = (int)((m >> (4 * i + 2)) & 3);
+        int r = ym - 2 + cy;
+        uint32_t fr = ((unsigned)r < (unsigned)TRL_ROWS) ? ((~(uint32_t)rows[r]) & 0x3FFu) : 0u;
+        v &= (fr << 2) >> cx;
+    }
+    return v & 0x3FFFu;
+}
+
+// all cells of `seed` plus every cell connected to one through left/right steps inside `m`
+// (the while-loop of move_generation.py:418-422 as two carry chains)
+__device__ __forceinline__ uint32_t row_fill(uint32_t m, uint32_t seed) {
+    uint32_t up = (((m + seed) ^ m) & m) | seed;
+    uint32_t mr = __brev(m) >> 16, sr = __brev(seed) >> 16;
+    uint32_t dn = (((mr + sr) ^ mr) & mr) | sr;
+    return up | (__brev(dn) >> 16);
+}
+
+// ---- flagged placements, kept in the reference's "last flagged writer wins" order ------------
+// (move_generation.py:671-677: unique_placements[key] = loc whenever loc is flagged)
+__device__ __forceinline__ void emit_flagged(MgScratch &S, bool emit, int rot, int my, uint32_t bit, int ul, int lane) {
+    uint64_t m = __ballot(emit);
+    while (m) {
+        int l = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+        if (lane == l) {
+            S.flagp[rot][my] |= (uint16_t)bit;
+            uint16_t u = S.ulp[rot][my];
+            S.ulp[rot][my] = ul ? (uint16_t)(u | bit) : (uint16_t)(u & ~bit);
+        }
+        wave_sync();
+    }
+}
+
+// ---- the search: _generate_moves_for_piece + _convolutional_algorithm +
+//      _convert_placements_to_policy (move_generation.py:107-153, 325-488, 650-749) -----------
+// One wavefront.  rows: the player's 40 board rows in LDS.  `need_spawn` = the piece comes out of
+// hold / next (Player.create_piece must succeed, player.py:37-44).  Writes the encoded
+// placements of this piece type in ascending order to out[] and returns their number;
+// *overflow is set when a cap was hit.
+__device__ int movegen_wave(const uint16_t *rows, int type, bool need_spawn, MgScratch &S,
+                            uint16_t *out, int out_cap, int lane, int *overflow) {
+    // validity maps + clear planes
+    for (int i = lane; i < 4 * MAP_H; i += 64) {
+        int r = i / MAP_H, ym = i - r * MAP_H;
+        S.valid[r][ym] = (uint16_t)valid_row(rows, type, r, ym);
+        S.visited[r][ym] = 0; S.present[r][ym] = 0; S.flagp[r][ym] = 0; S.ulp[r][ym] = 0;
+    }
+    // _get_highest_row / _set_starting_position (move_generation.py:164-180)
+    uint64_t occ = __ballot(lane < TRL_ROWS && rows[lane < TRL_ROWS ? lane : 0] != 0);
+    int highest = occ ? (__ffsll((unsigned long long)occ) - 1) : TRL_ROWS;
+    int box = C_BOX[type];
+    int sy = highest - box; if (sy < SPAWN_Y) sy = SPAWN_Y;
+    int sx = spawn_x(type);
+    wave_sync();
+
+    bool ok = (S.valid[0][sy + 2] >> (sx + 2)) & 1;                                  // :349-351
+    if (need_spawn) ok = ok && ((S.valid[0][SPAWN_Y + 2] >> (sx + 2)) & 1);           // player.py:40
+    ok = uni(ok);
+    int total = 0;
+    if (ok) {
+        const bool check_rot = (type != PO);
+        const bool isT = (type == PT);
+        const int ktab = (type == PI) ? 12 : 0;
+        int head = 0, tail = 1;
+        if (lane == 0) S.queue[0] = (uint16_t)((sx + 2) | ((sy + 2) << 4));
+        wave_sync();
+
+        while (head < tail) {
+            // classify up to 64 queued items at once
+            int idx = head + lane;
+            bool act = idx < tail;
+            uint32_t it = act ? S.queue[idx] : 0u;
+            int mx = it & 15, my = (it >> 4) & 63, rot = (it >> 10) & 3, fl = (it >> 12) & 1, ul = (it >> 13) & 1;
+            uint32_t bit = 1u << mx;
+            bool vis = act && (S.visited[rot][my] & bit);
+            bool stuck = (my + 1 >= MAP_H) || !(S.valid[rot][my + 1 < MAP_H ? my + 1 : my] & bit);
+            uint64_t unv = __ballot(act && !vis);
+            int first = unv ? (__ffsll((unsigned long long)unv) - 1) : 64;
+            // items up to and including the first unvisited one are popped now (:382-398)
+            emit_flagged(S, act && lane <= first && fl && stuck, rot, my, bit, ul, lane);
+            if (first == 64) { int n = tail - head; head += (n < 64 ? n : 64); continue; }
+            head += first + 1;
+
+            int fmx = uni(__shfl(mx, first, 64)), fmy = uni(__shfl(my, first, 64)), frot = uni(__shfl(rot, first, 64));
+            if (!((S.valid[frot][fmy] >> fmx) & 1)) continue;                          // :406-407
+
+            // scanline flood fill of this rotation state, one row per iteration (:409-425, :485-488)
+            uint32_t r = 1u << fmx;
+            const int col = lane / 3, dir = lane - col * 3 + 1;        // kick probe owned by this lane
+            const int nrot = (frot + dir) & 3;
+            const uint64_t kt = C_KICK[ktab + frot * 3 + (dir - 1)];
+            const int nk = (int)(kt >> 60);
+            for (int fy = fmy; fy < MAP_H && r; ++fy) {
+                uint32_t vr = S.valid[frot][fy];
+                uint32_t unvis = vr & ~(uint32_t)S.visited[frot][fy];
+                r = row_fill(unvis, r);
+                uint32_t next_vr = (fy + 1 < MAP_H) ? (uint32_t)S.valid[frot][fy + 1] : 0u;
+                uint32_t next_vis = (fy + 1 < MAP_H) ? (uint32_t)S.visited[frot][fy + 1] : 0u;
+                uint32_t blocked_down = r & ~next_vr;
+                uint32_t edges = blocked_down | (r & ~(vr << 1)) | (r & ~(vr >> 1));
+                if (lane == 0) {
+                    S.visited[frot][fy] |= (uint16_t)r;
+                    S.present[frot][fy] |= (uint16_t)blocked_down;                     // :439-440
+                }
+                // kick probes of this row: lane = 3 * column + (direction - 1)  (:443-481)
+                bool probe = check_rot && lane < 3 * MAP_W && ((edges >> col) & 1);
+                bool found = false, done = false;
+                int nmx = 0, nmy = 0, kidx = 0;
+#pragma unroll
+                for (int ki = 0; ki < 6; ki++) {
+                    int kx = (int)((kt >> (6 * ki)) & 7) - 2, ky = (int)((kt >> (6 * ki + 3)) & 7) - 2;
+                    int tx = col + kx, ty = fy - ky;
+                    bool in = (unsigned)tx < (unsigned)MAP_W && (unsigned)ty < (unsigned)MAP_H;
+                    bool fit = in && ((S.valid[nrot][in ? ty : 0] >> (in ? tx : 0)) & 1);
+                    if (probe && !done && ki < nk && fit) {
+                        done = true; found = (ty >= 2);                                 // new_y < 0: discard (:462-463)
+                        nmx = tx; nmy = ty; kidx = ki;
+                    }
+                }
+                int nul = (isT && dir != 2 && kidx == nk - 1) ? 1 : 0;
+                uint32_t nbit = 1u << nmx;
+                bool tvis = found && (S.visited[nrot][nmy] & nbit);
+                bool tstuck = (nmy + 1 >= MAP_H) || !(S.valid[nrot][nmy + 1 < MAP_H ? nmy + 1 : nmy] & nbit);
+                bool push = found && !tvis;
+                uint64_t pm = __ballot(push);
+                if (pm) {
+                    int pos = tail + lane_rank(pm, lane);
+                    if (push && pos < QCAP)
+                        S.queue[pos] = (uint16_t)(nmx | (nmy << 4) | (nrot << 10) | (1 << 12) | (nul << 13));
+                    tail += __popcll(pm);
+                    if (tail > QCAP) { *overflow = 1; tail = QCAP; }
+                }
+                emit_flagged(S, found && tvis && tstuck, nrot, nmy, nbit, nul, lane);   // :474-480
+                wave_sync();
+                r = r & next_vr & ~next_vis;
+            }
+        }
+
+        // placements -> policy planes -> ascending move list (:650-749, ai.py:1016-1024)
+        const int nrotp = C_NROT[type], base = C_PLANE_BASE[type];
+        const bool zsi = (type == PZ || type == PS || type == PI);
+        const int nts = isT ? 3 : 1;
+        for (int ts = 0; ts < nts; ts++) {
+            for (int ri = 0; ri < nrotp; ri++) {
+                uint32_t m = 0;
+                int row = lane;
+                if (row < TRL_POLICY_ROWS) {
+                    auto src = [&](int o, int my) -> uint32_t {
+                        uint32_t p = S.present[o][my], f = S.flagp[o][my], u = S.ulp[o][my];
+                        if (!isT) return p | f;
+                        return ts == 0 ? (p & ~f) : (ts == 1 ? (f & ~u) : (f & u));
+                    };
+                    m = src(ri, row + 2);
+                    if (zsi) {
+                        if (ri == 0) { if (row >= 1) m |= src(2, row + 1); }           // rot 2 -> rot 0, row + 1
+                        else m |= src(3, row + 2) >> 1;                                  // rot 3 -> rot 1, col - 1
+                    }
+                    m &= 0x7FFu;
+                }
+                int cnt = __popc(m);
+                int incl = wave_incl_scan(cnt, lane);
+                int off = total + incl - cnt;
+                int plane = base + ri + 4 * ts;
+                while (m) {
+                    int c = __ffs((int)m) - 1; m &= m - 1;
+                    if (off < out_cap) out[off] = (uint16_t)TRL_MOVE(plane, row, c);
+                    off++;
+                }
+                total += uni(__shfl(incl, 63, 64));
+            }
+        }
+        if (total > out_cap) { *overflow = 1; total = out_cap; }
+    }
+    wave_sync();
+    return total;
+}
+
+// piece types the generator looks at (move_generation.py:91-105 + the hold simulation of
+// :112-121): slot 0 = the active piece, slot 1 = what a hold would bring (held, else next)
+__device__ __forceinline__ void movegen_types(const trl_player_state &p, int *t0, int *t1) {
+    int p1 = p.piece;
+    int p2 = (p.held != P_NONE) ? p.held : (p.queue_len > 0 ? (int)(p.queue & 15) : P_NONE);
+    *t0 = p1;
+    *t1 = (p2 != p1) ? p2 : P_NONE;
+}
+
+// ---- stats.py:30-157 in integers --------------------------------------------------------------
+__device__ __forceinline__ void update_b2b_level(trl_player_state &p) {      // stats.py:30-43
+    int b = p.b2b, lvl = p.b2b_level, t;
+    t = (b >= 1370) ? 8 : (b >= 504) ? 7 : (b >= 185) ? 6 : (b >= 67) ? 5 : (b >= 24) ? 4 : (b >= 8) ? 3 : (b >= 3) ? 2 : (b >= 1) ? 1 : 0;
+    if (b >= -1 && lvl < t) lvl = t;
+    p.b2b_level = (uint8_t)lvl;
+}
+// floor(q(1 + c/4)) style terms are evaluated as integer products over 4 or 8
+__device__ int get_attack(trl_player_state &p, int ruleset, int rows, bool tspin, bool mini, bool all_clear) {
+    int attack = 0;
+    if (rows == 0) {
+        p.combo = 0;
+    } else {
+        int c4;      // 4 + combo
+        if (ruleset == TRL_RULESET_S1) {                                      // stats.py:49-86
+            bool is_b2b = (rows == 4) || tspin;
+            p.b2b = is_b2b ? (int16_t)(p.b2b + 1) : (int16_t)-1;
+            update_b2b_level(p);
+            int lvl = p.b2b_level; c4 = 4 + p.combo;
+            if (rows == 1) {
+                if (!tspin) { p.b2b = -1; attack += (p.combo + 2) >> 2; }
+                else if (mini) {
+                    if (p.b2b <= 0 && lvl <= 0) attack += (p.combo + 2) >> 2;
+                    else attack += (lvl * c4) >> 2;
+                } else attack += ((2 + lvl) * c4) >> 2;
+            } else {
+                int a2 = tspin ? (mini ? rows : 4 * rows) : 0;               // 2 * (2 rows tspin (1 - 3/4 mini))
+                int p2 = 2 * ((tspin ? 0 : (1 << (rows - 2))) + ((tspin || rows == 4) ? lvl : 0));
+                attack += (c4 * (a2 + p2)) >> 3;
+            }
+            p.combo += 1;
+            if (all_clear) attack += 10;
+        } else {                                                               // 's2', stats.py:88-133
+            bool is_b2b = tspin || mini || rows == 4;
+            if (is_b2b) p.b2b += 1;
+            else if (all_clear) { attack += 5; p.b2b += 1; }
+            else { if (p.b2b >= 4) attack += p.b2b; p.b2b = -1; }
+            update_b2b_level(p);
+            int lvl = p.b2b_level > 0 ? 1 : 0; c4 = 4 + p.combo;
+            if (rows == 1) {
+                if (!tspin) attack += (p.combo + 2) >> 2;
+                else if (mini) {
+                    if (p.b2b <= 0 && p.b2b_level <= 0) attack += (p.combo + 2) >> 2;
+                    else attack += (lvl * c4) >> 2;
+                } else attack += 2 + ((lvl * c4) >> 2);
+            } else {
+                int a2 = tspin ? (mini ? rows : 4 * rows) : 0;
+                int p2 = 2 * ((tspin ? 0 : (1 << (rows - 2))) + (is_b2b ? lvl : 0));
+                attack += (c4 * (a2 + p2)) >> 3;
+            }
+            p.combo += 1;
+        }
+    }
+    p.lines_sent += attack;                                                    // stats.py:135-136
+    p.lines_cleared += rows;
+    return attack;
+}
+
+// ---- player.py / game.py, one lane --------------------------------------------------------------
+__device__ __forceinline__ void create_piece(trl_player_state &p, int type) {          // player.py:37-44
+    if (pose_fits(p.rows, type, spawn_x(type), SPAWN_Y, 0)) p.piece = (uint8_t)type;
+    else p.game_over = 1;
+}
+__device__ __forceinline__ void create_next_piece(trl_player_state &p) {                // player.py:29-35
+    if (p.queue_len > 0) {
+        int next = (int)(p.queue & 15);
+        p.queue >>= 4; p.queue_len--;
+        create_piece(p, next);
+    } else if (p.held != P_NONE) {
+        int next = p.held; p.held = P_NONE;
+        create_piece(p, next);
+    }
+}
+__device__ __forceinline__ void hold_piece(trl_player_state &p) {                       // player.py:190-201
+    if (p.held == P_NONE) { p.held = p.piece; p.piece = P_NONE; create_next_piece(p); }
+    else { int temp = p.held; p.held = p.piece; create_piece(p, temp); }
+}
+__device__ __forceinline__ void garbage_pop(trl_player_state &p, int n) {               // n x pop(0)
+    for (int k = 0; k < n; k++) {
+        p.garbage[0] = (p.garbage[0] >> 4) | (p.garbage[1] << 60);
+        p.garbage[1] = (p.garbage[1] >> 4) | (p.garbage[2] << 60);
+        p.garbage[2] = (p.garbage[2] >> 4) | (p.garbage[3] << 60);
+        p.garbage[3] >>= 4;
+    }
+    p.garbage_len = (uint8_t)(p.garbage_len - n);
+}
+__device__ __forceinline__ bool garbage_push(trl_player_state &p, int col, int n) {     // extend([col] * n)
+    bool ovf = false;
+    for (int k = 0; k < n; k++) {
+        int i = p.garbage_len;
+        if (i >= TRL_MAX_GARBAGE) { ovf = true; break; }
+        p.garbage[i >> 4] |= (uint64_t)col << (4 * (i & 15));
+        p.garbage_len = (uint8_t)(i + 1);
+    }
+    return ovf;
+}
+
+// Queue.generate_bag + Game.add_bag_to_all (piece_queue.py:17-21, game.py:34-38)
+__device__ void add_bag_to_all(trl_game_state &g, uint64_t seed) {
+    for (int i = 0; i < 2; i++) {
+        uint64_t k = g.bag_ctr++;
+        uint32_t bag = 0x6543210u;                       // nibble j = j
+        for (int a = 6; a >= 1; a--) {
+            int b = (int)rng_below(seed, g.stream, TRL_RNG_BAG, 8 * k + (uint64_t)a, (uint32_t)(a + 1));
+            uint32_t va = (bag >> (4 * a)) & 15, vb = (bag >> (4 * b)) & 15;
+            bag = (bag & ~(15u << (4 * a)) & ~(15u << (4 * b))) | (va << (4 * b)) | (vb << (4 * a));
+        }
+        trl_player_state &p = g.p[i];
+        if (p.queue_len + 7 > TRL_MAX_QUEUE) { g.flags |= TRL_FLAG_OVERFLOW; continue; }
+        p.queue |= (uint64_t)bag << (4 * p.queue_len);
+        p.queue_len = (uint8_t)(p.queue_len + 7);
+    }
+}
+
+// Game.setup (game.py:28-32) on a zeroed slot
+__device__ void game_setup(trl_game_state &g, int ruleset, uint64_t seed, uint32_t stream) {
+    uint64_t *w = reinterpret_cast<uint64_t *>(&g);
+    for (int i = 0; i < (int)(sizeof(trl_game_state) / 8); i++) w[i] = 0;
+    g.stream = stream; g.ruleset = (uint8_t)ruleset;
+    for (int i = 0; i < 2; i++) { g.p[i].piece = P_NONE; g.p[i].held = P_NONE; g.p[i].b2b = -1; }
+    add_bag_to_all(g, seed);
+    for (int i = 0; i < 2; i++) create_next_piece(g.p[i]);
+}
+
+// Game.make_move(move, add_bag, add_history=False)  (game.py:40-98, player.py:109-188)
+__device__ void make_move(trl_game_state &g, uint64_t seed, int move, bool add_bag) {
+    trl_player_state &p = g.p[g.turn];
+    trl_player_state &o = g.p[1 - g.turn];
+    // Game.move_piece (game.py:40-64)
+    int pc = C_PLANE[TRL_MOVE_PLANE(move)];
+    int type = pc & 7, rot = (pc >> 3) & 3, ts = pc >> 5;
+    int x = TRL_MOVE_COL(move) - 2, y = TRL_MOVE_ROW(move);
+    if (p.piece == P_NONE || type != p.piece) hold_piece(p);
+    bool rot_flag = ts >= 1, last_kick = ts == 2;
+    if (p.game_over) return;                                                    // game.py:70
+    type = p.piece;
+    // Player.place_piece (player.py:109-188)
+    int place_y = y;                                                            // ghost_y, player.py:46-59
+    while (pose_fits(p.rows, type, x, place_y + 1, rot)) place_y++;
+    if (y != place_y) { rot_flag = false; last_kick = false; }                  // :115-118
+    bool tspin = false, mini = false, all_clear = false;
+    if (type == PT && rot_flag) {                                               // :127-140
+        bool f0 = !cell_free(p.rows, x, place_y), f1 = !cell_free(p.rows, x + 2, place_y);
+        bool f2 = !cell_free(p.rows, x + 2, place_y + 2), f3 = !cell_free(p.rows, x, place_y + 2);
+        tspin = ((int)f0 + (int)f1 + (int)f2 + (int)f3) >= 3;
+        bool front = (rot == 0 ? (f0 && f1) : rot == 1 ? (f1 && f2) : rot == 2 ? (f2 && f3) : (f3 && f0));
+        if (!front && !last_kick) mini = true;
+    }
+    if (g.ruleset == TRL_RULESET_S2 && !tspin) {                                // :143-151 (pose at the move's y)
+        bool mobile = pose_fits(p.rows, type, x - 1, y, rot) || pose_fits(p.rows, type, x + 1, y, rot) ||
+                      pose_fits(p.rows, type, x, y - 1, rot) || pose_fits(p.rows, type, x, y + 1, rot);
+        if (!mobile) mini = true;
+    }
+    if (!pose_fits(p.rows, type, x, place_y, rot)) { g.flags |= TRL_FLAG_BADMOVE; return; }   // not a legal pose
+    uint32_t mm = C_MINO[type * 4 + rot];                                       // :153-157 lock
+    uint64_t touched = 0;
+    for (int i = 0; i < 4; i++) {
+        int col = x + (int)((mm >> (4 * i)) & 3), row = place_y + (int)((mm >> (4 * i + 2)) & 3);
+        p.rows[row] |= (uint16_t)(1u << col);
+        touched |= 1ull << row;
+    }
+    p.piece = P_NONE;
+    int cleared = 0;                                                            // :161-175
+    uint64_t full = 0;
+    for (uint64_t t = touched; t; t &= t - 1) {
+        int row = __ffsll((unsigned long long)t) - 1;
+        if (p.rows[row] == 0x3FF) { full |= 1ull << row; cleared++; }
+    }
+    if (cleared) {
+        int dst = TRL_ROWS - 1;
+        for (int r = TRL_ROWS - 1; r >= 0; r--)
+            if (!((full >> r) & 1)) { p.rows[dst] = p.rows[r]; dst--; }
+        for (; dst >= 0; dst--) p.rows[dst] = 0;
+        uint32_t any = 0;                                                       // :177-178
+        for (int r = 0; r < TRL_ROWS; r++) any |= p.rows[r];
+        all_clear = (any == 0);
+    }
+    int attack = get_attack(p, g.ruleset, cleared, tspin, mini, all_clear);     // :180-186
+    p.pieces += 1;
+    // garbage_to_send = [column] * attack, then Game.check_garbage (game.py:100-117)
+    int send = attack, column = 0;
+    if (attack > 0) column = (int)rng_below(seed, g.stream, TRL_RNG_GARBAGE, g.garb_ctr++, 10);
+    int cancel = send < (int)p.garbage_len ? send : (int)p.garbage_len;
+    if (cancel > 0) { garbage_pop(p, cancel); send -= cancel; }
+    if (p.garbage_len > 0 && cleared == 0) {                                    // spawn_garbage, board.py:12-21
+        int n = p.garbage_len;
+        if (n > TRL_ROWS) { g.flags |= TRL_FLAG_OVERFLOW; n = TRL_ROWS; }
+        for (int r = 0; r < TRL_ROWS - n; r++) p.rows[r] = p.rows[r + n];
+        for (int i = 0; i < n; i++) {
+            int c = (int)((p.garbage[i >> 4] >> (4 * (i & 15))) & 15);
+            p.rows[TRL_ROWS - n + i] = (uint16_t)(0x3FFu & ~(1u << c));
+        }
+        p.garbage[0] = p.garbage[1] = p.garbage[2] = p.garbage[3] = 0; p.garbage_len = 0;
+    }
+    if (send > 0 && garbage_push(o, column, send)) g.flags |= TRL_FLAG_OVERFLOW;
+    create_next_piece(p);                                                       // game.py:80
+    if (add_bag && p.queue_len < 5) add_bag_to_all(g, seed);                    // game.py:82-83
+    g.turn ^= 1;
+    g.ply++;
+}
+
+__device__ __forceinline__ bool is_terminal(const trl_game_state &g) { return g.p[0].game_over || g.p[1].game_over; }
+__device__ __forceinline__ bool no_move(const trl_game_state &g) {
+    const trl_player_state &p = g.p[g.turn];
+    return p.piece == P_NONE && p.held == P_NONE;
+}
+
+}  // namespace trl

@@ -1,0 +1,380 @@
+// trl_engine.hip -- kernels + the C ABI of include/tetris_engine.h (gfx950 only, no CPU path).
+//
+// Kernel geometry: one 128-thread workgroup (two wavefronts) per game.  Wavefront w searches
+// the placements of piece slot w (active piece / hold-or-next piece); thread 0 then applies
+// the chosen placement.  The game's 320-byte state lives in LDS for the whole launch (the
+// rollout kernel keeps it there across plies), global traffic is one coalesced 320-byte read
+// and write per game per launch plus the move list when it is asked for.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include "../../include/tetris_engine.h"
+#include "trl_device.h"
+
+using namespace trl;
+
+static_assert(sizeof(trl_player_state) == 144, "trl_player_state layout");
+static_assert(sizeof(trl_game_state) == 320, "trl_game_state layout");
+
+namespace {
+
+constexpr int BLOCK = 128;
+constexpr int STATE_DW = sizeof(trl_game_state) / 4;    // 80
+
+struct BlockShared {
+    alignas(16) trl_game_state g;
+    MgScratch mg[2];
+    alignas(4) uint16_t list[2][TRL_MAX_LEGAL];
+    int cnt[2];
+    int order;          // which slot's list comes first in plane order
+    int overflow;
+    int chosen;         // rollout: encoded move picked for this ply (or -1)
+    int done;
+};
+
+__device__ __forceinline__ void load_state(BlockShared &sh, const trl_game_state *src, int tid) {
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
+    uint32_t *d = reinterpret_cast<uint32_t *>(&sh.g);
+    if (tid < STATE_DW) d[tid] = s[tid];
+}
+__device__ __forceinline__ void store_state(const BlockShared &sh, trl_game_state *dst, int tid) {
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(&sh.g);
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+    if (tid < STATE_DW) d[tid] = s[tid];
+}
+
+// legal placements of the side to move into sh.list / sh.cnt; all 128 threads call it.
+// Returns (uniformly) the total count; list order = slot sh.order first.
+__device__ int block_movegen(BlockShared &sh, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) { sh.overflow = 0; sh.cnt[0] = 0; sh.cnt[1] = 0; sh.order = 0; }
+    __syncthreads();
+    const trl_game_state &g = sh.g;
+    bool live = !is_terminal(g) && !no_move(g);
+    if (live) {
+        const trl_player_state &p = g.p[g.turn];
+        int t0, t1;
+        movegen_types(p, &t0, &t1);
+        int type = wave == 0 ? t0 : t1;
+        if (type != P_NONE) {
+            int ovf = 0;
+            int n = movegen_wave(p.rows, type, wave == 1, sh.mg[wave], sh.list[wave], TRL_MAX_LEGAL, lane, &ovf);
+            if (lane == 0) { sh.cnt[wave] = n; if (ovf) sh.overflow = 1; }
+        }
+        if (tid == 0) {
+            // planes of different piece types are disjoint ranges: lower base first (argwhere order)
+            int b0 = t0 != P_NONE ? C_PLANE_BASE[t0] : 99, b1 = t1 != P_NONE ? C_PLANE_BASE[t1] : 99;
+            sh.order = b1 < b0 ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    int total = sh.cnt[0] + sh.cnt[1];
+    if (total > TRL_MAX_LEGAL) { total = TRL_MAX_LEGAL; if (tid == 0) sh.overflow = 1; }
+    return total;
+}
+__device__ __forceinline__ uint16_t merged_move(const BlockShared &sh, int i) {
+    int a = sh.order, na = sh.cnt[a];
+    return i < na ? sh.list[a][i] : sh.list[1 - a][i - na];
+}
+
+// ---- kernels ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_reset(trl_game_state *states, const uint32_t *streams, int ruleset, uint64_t seed, int n) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    trl_game_state st;
+    game_setup(st, ruleset, seed, streams ? streams[g] : (uint32_t)g);
+    states[g] = st;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_legal(trl_game_state *states, uint16_t *counts, uint16_t *moves) {
+    __shared__ BlockShared sh;
+    const int tid = threadIdx.x, game = blockIdx.x;
+    load_state(sh, states + game, tid);
+    __syncthreads();
+    int total = block_movegen(sh, tid);
+    for (int i = tid; i < total; i += BLOCK) moves[(size_t)game * TRL_MAX_LEGAL + i] = merged_move(sh, i);
+    if (tid == 0) {
+        counts[game] = (uint16_t)total;
+        if (sh.overflow) states[game].flags |= TRL_FLAG_OVERFLOW;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_step(trl_game_state *states, const uint16_t *in_moves, uint64_t seed, int add_bag, int check_legal) {
+    __shared__ BlockShared sh;
+    const int tid = threadIdx.x, game = blockIdx.x;
+    const int move = in_moves[game];
+    if (move == TRL_MOVE_NONE) return;
+    load_state(sh, states + game, tid);
+    __syncthreads();
+    bool legal = true;
+    if (check_legal) {
+        int total = block_movegen(sh, tid);
+        bool mine = false;
+        for (int i = tid; i < total; i += BLOCK) mine |= (merged_move(sh, i) == move);
+        legal = __syncthreads_or(mine);
+    }
+    if (tid == 0) {
+        if (legal) make_move(sh.g, seed, move, add_bag != 0);
+        else sh.g.flags |= TRL_FLAG_BADMOVE;
+        if (check_legal && sh.overflow) sh.g.flags |= TRL_FLAG_OVERFLOW;
+    }
+    __syncthreads();
+    store_state(sh, states + game, tid);
+}
+
+// C2 workload: n_plies x { legal -> uniform pick -> make_move(add_bag) -> re-setup when finished }
+__global__ __launch_bounds__(BLOCK) void k_rollout(trl_game_state *states, uint64_t seed, int n_plies, int max_plies,
+                                                   unsigned long long *steps_total) {
+    __shared__ BlockShared sh;
+    const int tid = threadIdx.x, game = blockIdx.x;
+    load_state(sh, states + game, tid);
+    __syncthreads();
+    int steps = 0;
+    for (int k = 0; k < n_plies; k++) {
+        int total = block_movegen(sh, tid);
+        if (tid == 0) {
+            trl_game_state &g = sh.g;
+            if (sh.overflow) g.flags |= TRL_FLAG_OVERFLOW;
+            if (total > 0) {
+                int idx = (int)rng_below(seed, g.stream, TRL_RNG_POLICY, g.pol_ctr++, (uint32_t)total);
+                make_move(g, seed, merged_move(sh, idx), true);
+                steps++;
+            }
+            if (total == 0 || is_terminal(g) || (int)g.ply >= max_plies) {
+                uint32_t stream = g.stream + 0x01000000u, episode = g.episode + 1;
+                int ruleset = g.ruleset; uint8_t flags = g.flags;
+                game_setup(g, ruleset, seed, stream);
+                g.episode = episode; g.flags = flags;
+            }
+        }
+        __syncthreads();
+    }
+    store_state(sh, states + game, tid);
+    if (tid == 0 && steps_total) atomicAdd(steps_total, (unsigned long long)steps);
+}
+
+// exhaustive check of the integer attack formulas against stats.py (tests only)
+__global__ void k_attack_table(const int16_t *rows, int n, int16_t *out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int16_t *r = rows + 8 * i;
+    trl_player_state p;
+    memset(&p, 0, sizeof p);
+    p.combo = r[5]; p.b2b = r[6]; p.b2b_level = (uint8_t)r[7];
+    int a = get_attack(p, r[0], r[1], r[2] != 0, r[3] != 0, r[4] != 0);
+    out[4 * i + 0] = (int16_t)a; out[4 * i + 1] = p.combo; out[4 * i + 2] = p.b2b; out[4 * i + 3] = p.b2b_level;
+}
+
+}  // namespace
+
+// ---- host side -----------------------------------------------------------------------------------
+struct trl_engine {
+    trl_config cfg;
+    hipStream_t stream;
+    bool own_stream;
+    trl_game_state *d_states;
+    uint16_t *d_counts, *d_moves, *d_in_moves;
+    unsigned long long *d_steps;
+    hipEvent_t ev0, ev1;
+    bool have_reset;
+    float last_ms;
+};
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char *fmt, const char *detail) {
+    snprintf(g_err, sizeof g_err, fmt, detail);
+    return code;
+}
+#define HIPCHK(call)                                                        \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) return fail(TRL_E_HIP, #call ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" {
+
+const char *trl_last_error(void) { return g_err; }
+const char *trl_version(void) { return "trl-hip 0.1 (gfx950)"; }
+
+int trl_engine_create(const trl_config *cfg, trl_engine **out) {
+    if (!cfg || !out || cfg->n_games <= 0 || (cfg->ruleset != TRL_RULESET_S1 && cfg->ruleset != TRL_RULESET_S2))
+        return fail(TRL_E_INVALID, "trl_engine_create: %s", "bad config");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device >= ndev)
+        return fail(TRL_E_NO_DEVICE, "trl_engine_create: %s", "no HIP device visible (the engine has no CPU path)");
+    HIPCHK(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(TRL_E_NO_DEVICE, "trl_engine_create: device is %s, this library is built for gfx950 only", prop.gcnArchName);
+    trl_engine *h = new (std::nothrow) trl_engine();
+    if (!h) return fail(TRL_E_INVALID, "trl_engine_create: %s", "out of host memory");
+    memset(h, 0, sizeof *h);
+    h->cfg = *cfg;
+    if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; h->own_stream = false; }
+    else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    size_t n = (size_t)cfg->n_games;
+    HIPCHK(hipMalloc(&h->d_states, n * sizeof(trl_game_state)));
+    HIPCHK(hipMalloc(&h->d_counts, n * sizeof(uint16_t)));
+    HIPCHK(hipMalloc(&h->d_moves, n * TRL_MAX_LEGAL * sizeof(uint16_t)));
+    HIPCHK(hipMalloc(&h->d_in_moves, n * sizeof(uint16_t)));
+    HIPCHK(hipMalloc(&h->d_steps, sizeof(unsigned long long)));
+    HIPCHK(hipEventCreate(&h->ev0));
+    HIPCHK(hipEventCreate(&h->ev1));
+    *out = h;
+    return TRL_OK;
+}
+
+void trl_engine_destroy(trl_engine *h) {
+    if (!h) return;
+    hipSetDevice(h->cfg.device);
+    hipStreamSynchronize(h->stream);
+    hipFree(h->d_states); hipFree(h->d_counts); hipFree(h->d_moves); hipFree(h->d_in_moves); hipFree(h->d_steps);
+    hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int trl_set_stream(trl_engine *h, void *hip_stream) {
+    if (!h) return fail(TRL_E_INVALID, "%s", "null engine");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->own_stream) { HIPCHK(hipStreamDestroy(h->stream)); h->own_stream = false; }
+    if (hip_stream) h->stream = (hipStream_t)hip_stream;
+    else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    return TRL_OK;
+}
+
+int trl_env_reset(trl_engine *h, const uint32_t *stream_ids) {
+    if (!h) return fail(TRL_E_INVALID, "%s", "null engine");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int n = h->cfg.n_games;
+    uint32_t *d_streams = nullptr;
+    if (stream_ids) {
+        HIPCHK(hipMalloc(&d_streams, (size_t)n * 4));
+        HIPCHK(hipMemcpyAsync(d_streams, stream_ids, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    hipLaunchKernelGGL(k_reset, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream,
+                       h->d_states, d_streams, h->cfg.ruleset, h->cfg.seed, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (d_streams) HIPCHK(hipFree(d_streams));
+    h->have_reset = true;
+    return TRL_OK;
+}
+
+int trl_env_get_state(trl_engine *h, trl_game_state *host_out) {
+    if (!h || !host_out) return fail(TRL_E_INVALID, "%s", "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemcpyAsync(host_out, h->d_states, (size_t)h->cfg.n_games * sizeof(trl_game_state), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return TRL_OK;
+}
+
+int trl_env_set_state(trl_engine *h, const trl_game_state *host_in) {
+    if (!h || !host_in) return fail(TRL_E_INVALID, "%s", "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemcpyAsync(h->d_states, host_in, (size_t)h->cfg.n_games * sizeof(trl_game_state), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_reset = true;
+    return TRL_OK;
+}
+
+int trl_env_state_dev(trl_engine *h, void **dev_out) {
+    if (!h || !dev_out) return fail(TRL_E_INVALID, "%s", "null argument");
+    *dev_out = h->d_states;
+    return TRL_OK;
+}
+
+int trl_env_legal_dev(trl_engine *h, void **dev_counts, void **dev_moves) {
+    if (!h) return fail(TRL_E_INVALID, "%s", "null engine");
+    if (dev_counts) *dev_counts = h->d_counts;
+    if (dev_moves) *dev_moves = h->d_moves;
+    return TRL_OK;
+}
+
+int trl_env_legal_moves(trl_engine *h, uint16_t *host_counts, uint16_t *host_moves) {
+    if (!h) return fail(TRL_E_INVALID, "%s", "null engine");
+    if (!h->have_reset) return fail(TRL_E_STATE, "%s", "trl_env_legal_moves before trl_env_reset / trl_env_set_state");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int n = h->cfg.n_games;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(k_legal, dim3(n), dim3(BLOCK), 0, h->stream, h->d_states, h->d_counts, h->d_moves);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    if (host_counts) HIPCHK(hipMemcpyAsync(host_counts, h->d_counts, (size_t)n * 2, hipMemcpyDeviceToHost, h->stream));
+    if (host_moves) HIPCHK(hipMemcpyAsync(host_moves, h->d_moves, (size_t)n * TRL_MAX_LEGAL * 2, hipMemcpyDeviceToHost, h->stream));
+    if (host_counts || host_moves) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    }
+    return TRL_OK;
+}
+
+int trl_env_step_dev(trl_engine *h, const void *dev_moves, int add_bag, int check_legal) {
+    if (!h || !dev_moves) return fail(TRL_E_INVALID, "%s", "null argument");
+    if (!h->have_reset) return fail(TRL_E_STATE, "%s", "trl_env_step before trl_env_reset / trl_env_set_state");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(k_step, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->d_states,
+                       (const uint16_t *)dev_moves, h->cfg.seed, add_bag, check_legal);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    return TRL_OK;
+}
+
+int trl_env_step(trl_engine *h, const uint16_t *host_moves, int add_bag, int check_legal) {
+    if (!h || !host_moves) return fail(TRL_E_INVALID, "%s", "null argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemcpyAsync(h->d_in_moves, host_moves, (size_t)h->cfg.n_games * 2, hipMemcpyHostToDevice, h->stream));
+    int rc = trl_env_step_dev(h, h->d_in_moves, add_bag, check_legal);
+    if (rc != TRL_OK) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    return TRL_OK;
+}
+
+int trl_env_rollout_random(trl_engine *h, int n_plies, int max_plies, uint64_t *steps_out) {
+    if (!h || n_plies < 0 || max_plies <= 0) return fail(TRL_E_INVALID, "%s", "bad argument");
+    if (!h->have_reset) return fail(TRL_E_STATE, "%s", "trl_env_rollout_random before trl_env_reset / trl_env_set_state");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemsetAsync(h->d_steps, 0, sizeof(unsigned long long), h->stream));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipLaunchKernelGGL(k_rollout, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->d_states, h->cfg.seed,
+                       n_plies, max_plies, h->d_steps);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    if (steps_out) {
+        unsigned long long s = 0;
+        HIPCHK(hipMemcpyAsync(&s, h->d_steps, sizeof s, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+        *steps_out = s;
+    }
+    return TRL_OK;
+}
+
+int trl_last_kernel_ms(trl_engine *h, float *ms_out) {
+    if (!h || !ms_out) return fail(TRL_E_INVALID, "%s", "null argument");
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
+    *ms_out = h->last_ms;
+    return TRL_OK;
+}
+
+// test hook (declared in tests only): integer attack formulas, rows int16[n][8] -> out int16[n][4]
+int trl_debug_attack_table(const int16_t *host_rows, int n, int16_t *host_out) {
+    int16_t *d_rows = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc(&d_rows, (size_t)n * 16));
+    HIPCHK(hipMalloc(&d_out, (size_t)n * 8));
+    HIPCHK(hipMemcpy(d_rows, host_rows, (size_t)n * 16, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_attack_table, dim3((n + 255) / 256), dim3(256), 0, 0, d_rows, n, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(host_out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(d_rows));
+    HIPCHK(hipFree(d_out));
+    return TRL_OK;
+}
+
+}  // extern "C"
