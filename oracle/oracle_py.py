@@ -18,7 +18,7 @@ POLICY_SIZE = 27 * 39 * 11
 
 
 def build(force=False):
-    src = [os.path.join(HERE, f) for f in ("tetris_oracle.c", "tetris_oracle.h")]
+    src = [os.path.join(HERE, f) for f in ("tetris_oracle.c", "tetris_oracle_mcts.c", "tetris_oracle.h")]
     src.append(os.path.join(os.path.dirname(HERE), "include", "tetris_engine.h"))
     if (not force and os.path.isfile(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in src)):
@@ -157,3 +157,77 @@ def attack_table(rows):
 def mask_to_moves(mask):
     idx = np.argwhere(mask)
     return np.array([(int(p) << 10) | (int(r) << 4) | int(c) for p, r, c in idx], dtype=np.uint16)
+
+
+# ---- search ------------------------------------------------------------------------------------
+class MctsConfig(C.Structure):
+    _fields_ = [("max_iter", C.c_int), ("cpuct", C.c_double), ("dpuct", C.c_double),
+                ("fpu_reduction", C.c_int), ("fpu_value", C.c_double),
+                ("use_root_softmax", C.c_int), ("root_softmax_temp", C.c_double), ("temperature", C.c_double),
+                ("training", C.c_int), ("use_playout_cap", C.c_int),
+                ("playout_cap_chance", C.c_double), ("playout_cap_mult", C.c_double),
+                ("use_dirichlet", C.c_int), ("dir_alpha", C.c_double), ("dir_s", C.c_double), ("dir_expl", C.c_double),
+                ("use_dir_s", C.c_int), ("use_forced", C.c_int), ("c_forced", C.c_double)]
+
+
+class MctsResult(C.Structure):
+    _fields_ = [("move", C.c_int), ("save_move", C.c_int), ("max_iterations", C.c_int),
+                ("n_root_children", C.c_int), ("n_nodes", C.c_int), ("root_visit", C.c_int),
+                ("root_moves", C.c_uint16 * MAX_LEGAL), ("root_visits", C.c_int * MAX_LEGAL),
+                ("root_q", C.c_double * MAX_LEGAL), ("root_p", C.c_double * MAX_LEGAL)]
+
+
+def default_mcts_config(**kw):
+    """Config() defaults of the reference (ai.py:63-138) with MAX_ITER=160"""
+    c = MctsConfig(max_iter=160, cpuct=0.75, dpuct=1.0, fpu_reduction=1, fpu_value=0.1, use_root_softmax=1,
+                   root_softmax_temp=1.1, temperature=0.1, training=0, use_playout_cap=1, playout_cap_chance=0.25,
+                   playout_cap_mult=5.0, use_dirichlet=1, dir_alpha=0.1, dir_s=25.0, dir_expl=0.25, use_dir_s=1,
+                   use_forced=0, c_forced=1.0)
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def mcts_stub(game, cfg):
+    """to_mcts with the stub evaluator on an OracleGame; returns a dict"""
+    L = lib()
+    L.to_mcts_stub.argtypes = [C.c_void_p, C.POINTER(MctsConfig), C.POINTER(MctsResult)]
+    res = MctsResult()
+    rc = L.to_mcts_stub(game._buf, C.byref(cfg), C.byref(res))
+    assert rc == 0
+    n = res.n_root_children
+    return dict(move=res.move, save=res.save_move, max_iterations=res.max_iterations, n_nodes=res.n_nodes,
+                root_visit=res.root_visit, moves=np.array(res.root_moves[:n], dtype=np.uint16),
+                visits=np.array(res.root_visits[:n], dtype=np.int32), q=np.array(res.root_q[:n]),
+                p=np.array(res.root_p[:n]))
+
+
+def stub_eval_state(state):
+    st = np.ascontiguousarray(state, dtype=np.uint8)
+    v = C.c_float()
+    pol = np.zeros(POLICY_SIZE, dtype=np.float32)
+    L = lib()
+    L.to_stub_eval_state.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_void_p]
+    L.to_stub_eval_state(st.ctypes.data, C.byref(v), pol.ctypes.data)
+    return float(v.value), pol.reshape(27, 39, 11)
+
+
+def play_game_stub(ruleset, seed, stream, cfg, max_log=2048, max_children=2048 * 160):
+    """to_play_game with the stub evaluator; returns per-ply logs"""
+    L = lib()
+    g = OracleGame(ruleset=ruleset, seed=seed, stream=stream)
+    ply_state = np.zeros((max_log, STATE_BYTES), dtype=np.uint8)
+    ply_move = np.zeros(max_log, dtype=np.uint16)
+    ply_save = np.zeros(max_log, dtype=np.int32)
+    ply_nchild = np.zeros(max_log, dtype=np.int32)
+    child_moves = np.zeros(max_children, dtype=np.uint16)
+    child_visits = np.zeros(max_children, dtype=np.int32)
+    winner = C.c_int()
+    L.to_play_game_stub.argtypes = [C.c_void_p, C.POINTER(MctsConfig), C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.POINTER(C.c_int)]
+    n = L.to_play_game_stub(g._buf, C.byref(cfg), max_log, ply_state.ctypes.data, ply_move.ctypes.data,
+                            ply_save.ctypes.data, ply_nchild.ctypes.data, child_moves.ctypes.data,
+                            child_visits.ctypes.data, max_children, C.byref(winner))
+    tot = int(ply_nchild[:n].sum())
+    return dict(plies=n, winner=winner.value, final=g.export(), ply_state=ply_state[:n], ply_move=ply_move[:n],
+                ply_save=ply_save[:n], ply_nchild=ply_nchild[:n], child_moves=child_moves[:tot],
+                child_visits=child_visits[:tot])

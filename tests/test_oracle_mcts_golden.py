@@ -1,0 +1,74 @@
+"""The oracle's search (oracle/tetris_oracle_mcts.c) against the reference's MCTS run with the
+stub evaluator (oracle/gen_golden_mcts.py): root children, visit counts, Q, priors, chosen move,
+tree size, and the running garbage-draw counter after the search."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as op
+
+VARIANTS = {
+    "eval": dict(training=0),
+    "train": dict(training=1),
+    "train_nosoftmax": dict(training=1, use_root_softmax=0),
+    "eval_absfpu": dict(training=0, fpu_reduction=0, fpu_value=0.4),
+}
+
+
+def test_stub_evaluator_matches_harness():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import importlib
+    g = op.OracleGame(ruleset=2, seed=1, stream=5)
+    g.rollout_random(7)
+    st = g.export()
+    v, pol = op.stub_eval_state(st)
+    # independent numpy statement of the stub (the one the fixtures were generated with)
+    gm = importlib.import_module("gen_golden_mcts")
+    v2, pol2 = gm.stub_eval_state(bytes(st))
+    assert v == v2 and np.array_equal(pol, pol2)
+    assert (pol == 0).mean() > 0.03 and 0 <= v < 1
+
+
+def test_mcts_single_searches(golden_dir):
+    d = np.load(os.path.join(golden_dir, "mcts.npz"))
+    seed = int(d["seed"])
+    names = [str(x) for x in d["variant_names"]]
+    off = np.concatenate([[0], np.cumsum(d["child_counts"])])
+    for i in range(d["states"].shape[0]):
+        cfg = op.default_mcts_config(**VARIANTS[names[d["variant"][i]]])
+        g = op.OracleGame(state=d["states"][i], seed=seed)
+        r = op.mcts_stub(g, cfg)
+        sl = slice(off[i], off[i + 1])
+        tag = "case %d (%s)" % (i, names[d["variant"][i]])
+        assert np.array_equal(r["moves"], d["child_moves"][sl]), tag
+        assert np.array_equal(r["visits"], d["child_visits"][sl]), tag
+        assert r["move"] == d["move"][i] and r["save"] == d["save"][i], tag
+        assert r["n_nodes"] == d["n_nodes"][i] and r["root_visit"] == d["root_visit"][i], tag
+        assert np.array_equal(r["q"], d["child_q"][sl]), tag          # fp64 bit patterns
+        assert np.array_equal(r["p"], d["child_p"][sl]), tag
+        assert int(g.export()[296:300].view("<u4")[0]) == d["garb_ctr"][i], tag
+
+
+def test_play_game_matches_reference(golden_dir):
+    """play_game (ai.py:1570-1699) with the stub evaluator: every ply's pre-search state, chosen
+    move, save flag and root (move, visits) vector of three reference games."""
+    d = np.load(os.path.join(golden_dir, "selfplay.npz"))
+    seed = int(d["seed"])
+    p_off = np.concatenate([[0], np.cumsum(d["game_plies"])])
+    c_off = np.concatenate([[0], np.cumsum(d["ply_child_counts"])])
+    for gi in range(d["game_ruleset"].shape[0]):
+        cfg = op.default_mcts_config(max_iter=int(d["max_iter"]), training=int(d["game_training"][gi]))
+        r = op.play_game_stub(int(d["game_ruleset"][gi]), seed, int(d["game_stream"][gi]), cfg)
+        assert r["plies"] == d["game_plies"][gi]
+        sl = slice(p_off[gi], p_off[gi + 1])
+        a, b = r["ply_state"].copy(), d["ply_state"][sl].copy()
+        a[:, 304:308] = 0; b[:, 304:308] = 0
+        assert np.array_equal(a, b), "pre-search states, game %d" % gi
+        assert np.array_equal(r["ply_move"], d["ply_move"][sl])
+        assert np.array_equal(r["ply_save"], d["ply_save"][sl])
+        assert np.array_equal(r["ply_nchild"], d["ply_child_counts"][sl])
+        csl = slice(c_off[p_off[gi]], c_off[p_off[gi + 1]])
+        assert np.array_equal(r["child_moves"], d["ply_child_moves"][csl])
+        assert np.array_equal(r["child_visits"], d["ply_child_visits"][csl])
