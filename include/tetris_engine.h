@@ -177,6 +177,101 @@ int  trl_env_rollout_random(trl_engine *h, int n_plies, int max_plies, uint64_t 
  * engine's stream (what bench.py's roofline block is computed from)                          */
 int  trl_last_kernel_ms(trl_engine *h, float *ms_out);
 
+
+/* ==== search: MCTS(config, game, net) for every game slot (ai.py:299-659) ========================
+ *
+ * Every slot runs the reference's sequential PUCT search on its own GPU-resident tree; slots
+ * advance in lockstep "ticks", one simulation per slot per tick, so that the leaf evaluations
+ * of all slots form one batch for the policy/value net -- the cross-game coalescing of the
+ * reference's BatchedEvaluator (ai.py:662-742) without the host in the loop:
+ *
+ *     trl_mcts_select(h, grids, vec)      selection + Game.copy/make_move + legal moves + game_to_X
+ *     <net forward on grids/vec>          -> values[n], policy[n][11583] (softmaxed, ai.py:1318)
+ *     trl_mcts_expand(h, values, policy)  expansion, root noise, backup, FPU refresh; on the last
+ *                                         simulation of a search: move choice, record, make_move,
+ *                                         game end / re-setup (play_game, ai.py:1610-1695)
+ *
+ * Searches of different slots finish at different ticks (playout-cap randomisation gives 400
+ * or 80 simulations at MAX_ITER=160); a slot that finishes starts its next search on the next
+ * tick.  Arithmetic follows the reference under numpy >= 2 (float32 PUCT terms below the root,
+ * fp64 at the root and for value sums); see DESIGN.md.
+ *
+ * Extra RNG purposes (counter = ply of the root position unless noted):
+ *   p = 3 playout-cap coin, p = 4 temperature pick: uniform double ((u64 >> 11) + 0.5) * 2^-53;
+ *   p = 5 root noise, gamma(alpha) by Marsaglia-Tsang on alpha + 1 with the u^(1/alpha) boost,
+ *         counter ((ply * 512 + child) * 64 + attempt) * 4 + k.
+ */
+typedef struct trl_mcts_config {      /* Config fields the search reads (ai.py:63-138) */
+    int32_t max_iter;                 /* MAX_ITER */
+    int32_t training;                 /* Config.training */
+    int32_t fpu_reduction;            /* FpuStrategy == 'reduction' (else 'absolute') */
+    int32_t use_root_softmax;
+    int32_t use_playout_cap;          /* use_playout_cap_randomization */
+    int32_t use_dirichlet;            /* use_dirichlet_noise */
+    int32_t use_dir_s;                /* use_dirichlet_s */
+    int32_t use_forced;               /* use_forced_playouts_and_policy_target_pruning (selection part) */
+    int32_t save_all;                 /* Config.save_all */
+    int32_t max_nodes;                /* tree capacity per slot (0 = default 65536) */
+    int32_t record_capacity;          /* records held on the device between drains (0 = default) */
+    int32_t auto_reset;               /* 1: a finished game is set up again on a fresh stream */
+    double  cpuct, dpuct;             /* CPUCT, DPUCT */
+    double  fpu_value;                /* FpuValue */
+    double  root_softmax_temp;        /* RootSoftmaxTemp */
+    double  temperature;
+    double  playout_cap_chance, playout_cap_mult;
+    double  dir_alpha, dir_s, dir_expl;   /* DIRICHLET_ALPHA, DIRICHLET_S, DIRICHLET_EXPLORATION */
+    double  c_forced;                 /* CForcedPlayout */
+} trl_mcts_config;
+
+#define TRL_GRID_FLOATS   (TRL_ROWS * TRL_COLS)        /* 400 */
+#define TRL_VEC_FLOATS    105   /* a_pieces 49, a_b2b, a_combo, a_garbage, o_pieces 49, o_b2b, o_combo, o_garbage, color */
+
+/* one saved move or one game end, as handed to the host (trl_mcts_drain_records) */
+#define TRL_REC_MOVE      0
+#define TRL_REC_GAME_END  1
+typedef struct trl_record {
+    uint32_t slot;                    /* game slot */
+    uint32_t episode;                 /* games finished in this slot before this one */
+    uint32_t ply;                     /* ply of the root position (TRL_REC_MOVE) / plies played (GAME_END) */
+    uint16_t n_children;
+    uint8_t  kind;                    /* TRL_REC_MOVE / TRL_REC_GAME_END */
+    int8_t   winner;                  /* GAME_END: Game.winner (game.py:217-225), -1 = draw */
+    uint16_t chosen;                  /* MOVE: the move played */
+    uint8_t  saved;                   /* MOVE: save_move or save_all (ai.py:1613) */
+    uint8_t  pad_;
+    trl_game_state state;             /* MOVE: the position searched (game_to_X input, ai.py:1617); GAME_END: final */
+    uint16_t moves[TRL_MAX_LEGAL];    /* root children: encoded moves ... */
+    uint16_t visits[TRL_MAX_LEGAL];   /* ... and visit counts (search_statistics input, ai.py:1330) */
+} trl_record;                         /* 2392 bytes (state is 8-byte aligned at offset 24) */
+
+typedef struct trl_mcts_stats {
+    uint64_t ticks;                   /* select/expand pairs executed */
+    uint64_t simulations;             /* simulations executed over all slots */
+    uint64_t moves;                   /* searches completed = moves played */
+    uint64_t games;                   /* games finished */
+    uint64_t records_dropped;         /* records lost because the device buffer was full */
+    uint32_t max_nodes_used;          /* high-water mark of tree nodes in any slot */
+    uint32_t overflow;                /* a slot exceeded max_nodes (its search was cut short) */
+} trl_mcts_stats;
+
+/* attach search state to an engine whose games are set up (trl_env_reset / trl_env_set_state) */
+int  trl_mcts_create(trl_engine *h, const trl_mcts_config *cfg);
+/* tick part A.  dev_grids: float[2][n_games][40][10] (side to move first, then opponent --
+ * simplify_grid, ai.py:1364-1377), dev_vec: float[n_games][TRL_VEC_FLOATS]; both device pointers. */
+int  trl_mcts_select(trl_engine *h, float *dev_grids, float *dev_vec);
+/* tick part B.  dev_values: float[n_games] (sigmoid value head), dev_policy: float[n_games][11583]
+ * softmaxed policy, both as evaluate() returns them (ai.py:1222-1319). */
+int  trl_mcts_expand(trl_engine *h, const float *dev_values, const float *dev_policy);
+/* copy out and clear the pending records (host buffer of `cap` records); returns the count in *n_out */
+int  trl_mcts_drain_records(trl_engine *h, trl_record *host_out, int cap, int *n_out);
+int  trl_mcts_get_stats(trl_engine *h, trl_mcts_stats *host_out);
+/* leaf positions of the current tick (after trl_mcts_select), n_games canonical states; and per
+ * slot {simulation index, simulations of this search, leaf kind 0 expand / 1 eval only / 2 terminal,
+ * legal count} -- what a host-side evaluator or a test needs */
+int  trl_mcts_leaf_states(trl_engine *h, trl_game_state *host_out, int32_t *host_info /* [n_games][4] */);
+/* root children of every slot's current tree: counts[n], moves / visits [n][TRL_MAX_LEGAL], q / p as fp64 */
+int  trl_mcts_root_children(trl_engine *h, int32_t *counts, uint16_t *moves, int32_t *visits, double *q, double *p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,176 @@
+"""GPU search + game driver (through the C ABI) against the reference's MCTS / play_game fixtures
+and the oracle, using the deterministic stub evaluator on the device.  Visit counts, chosen moves,
+save flags and per-ply states are compared exactly; Q / P to 1e-12 (device libm vs glibc in
+log/exp of the root softmax and the gamma sampler)."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as op
+import tetris_rl_amd as trl
+from tetris_rl_amd import records
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = {
+    "eval": dict(training=0),
+    "train": dict(training=1),
+    "train_nosoftmax": dict(training=1, use_root_softmax=0),
+    "eval_absfpu": dict(training=0, fpu_reduction=0, fpu_value=0.4),
+}
+
+
+class StubSearch:
+    """ticks an Engine with the on-device stub evaluator"""
+
+    def __init__(self, eng, cfg):
+        import torch
+        self.torch = torch
+        self.eng = eng
+        n = eng.n_games
+        dev = torch.device("cuda", 0)
+        self.grids = torch.zeros((2, n, 400), dtype=torch.float32, device=dev)
+        self.vec = torch.zeros((n, 105), dtype=torch.float32, device=dev)
+        self.values = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.policy = torch.zeros((n, 11583), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        eng.mcts_create(cfg)
+        L = trl.load_library()
+        L.trl_debug_stub_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        self.L = L
+
+    def tick(self):
+        e = self.eng
+        e.mcts_select(self.grids.data_ptr(), self.vec.data_ptr())
+        assert self.L.trl_debug_stub_eval(e._h, self.values.data_ptr(), self.policy.data_ptr()) == 0
+        e.mcts_expand(self.values.data_ptr(), self.policy.data_ptr())
+
+
+def test_single_searches_match_reference(golden_dir):
+    d = np.load(os.path.join(golden_dir, "mcts.npz"))
+    names = [str(x) for x in d["variant_names"]]
+    off = np.concatenate([[0], np.cumsum(d["child_counts"])])
+    for vi, name in enumerate(names):
+        idx = np.nonzero(d["variant"] == vi)[0]
+        eng = trl.Engine(len(idx), seed=int(d["seed"]))
+        eng.set_state(d["states"][idx])
+        s = StubSearch(eng, trl.mcts_config(max_iter=160, auto_reset=0, **VARIANTS[name]))
+        first = {}
+        for t in range(400):
+            s.tick()
+            recs = eng.mcts_drain_records()
+            for r in recs:
+                if r["kind"] == trl.REC_MOVE and int(r["slot"]) not in first:
+                    first[int(r["slot"])] = r.copy()
+            if len(first) == len(idx):
+                break
+        assert len(first) == len(idx)
+        for j, ci in enumerate(idx):
+            r = first[j]
+            sl = slice(off[ci], off[ci + 1])
+            n = int(r["n_children"])
+            tag = "%s case %d" % (name, ci)
+            assert n == d["child_counts"][ci], tag
+            assert np.array_equal(r["moves"][:n], d["child_moves"][sl]), tag
+            assert np.array_equal(r["visits"][:n].astype(np.int32), d["child_visits"][sl]), tag
+            assert int(r["chosen"]) == d["move"][ci] and int(r["saved"]) == d["save"][ci], tag
+            assert np.array_equal(r["state"], d["states"][ci]), tag
+        st = eng.mcts_stats()
+        assert st["overflow"] == 0 and st["records_dropped"] == 0
+
+
+def test_root_q_and_p_after_full_search(golden_dir):
+    """one eval-mode search stopped right after its last simulation: Q and P of the root children"""
+    d = np.load(os.path.join(golden_dir, "mcts.npz"))
+    off = np.concatenate([[0], np.cumsum(d["child_counts"])])
+    idx = np.nonzero(d["variant"] == 0)[0][:6]
+    eng = trl.Engine(len(idx), seed=int(d["seed"]))
+    eng.set_state(d["states"][idx])
+    # max_iter 161: after 160 ticks the trees equal the reference's 160-simulation trees
+    s = StubSearch(eng, trl.mcts_config(max_iter=161, training=0, auto_reset=0))
+    for t in range(160):
+        s.tick()
+    counts, moves, visits, q, p = eng.mcts_root_children()
+    for j, ci in enumerate(idx):
+        sl = slice(off[ci], off[ci + 1])
+        n = counts[j]
+        assert np.array_equal(visits[j, :n], d["child_visits"][sl])
+        assert np.allclose(q[j, :n], d["child_q"][sl], rtol=1e-12, atol=1e-15)
+        assert np.allclose(p[j, :n], d["child_p"][sl], rtol=1e-12, atol=1e-300)
+
+
+def _play_until_done(eng, s, max_ticks):
+    out = []
+    for t in range(max_ticks):
+        s.tick()
+        if t % 64 == 63 or t == max_ticks - 1:
+            out.append(eng.mcts_drain_records())
+            if any((r["kind"] == trl.REC_GAME_END).any() for r in out if len(r)):
+                ends = sum(int((r["kind"] == trl.REC_GAME_END).sum()) for r in out)
+                if ends == eng.n_games:
+                    break
+    return np.concatenate(out) if out else np.zeros(0, dtype=trl.RECORD_DTYPE)
+
+
+def test_selfplay_games_match_reference_play_game(golden_dir):
+    """three whole reference games (play_game + MCTS, stub evaluator): every ply's searched
+    position, chosen move, save flag, root (move, N) vector -- and the 13-field records rebuilt
+    from the device's record stream hash to the reference's JSON."""
+    d = np.load(os.path.join(golden_dir, "selfplay.npz"))
+    p_off = np.concatenate([[0], np.cumsum(d["game_plies"])])
+    c_off = np.concatenate([[0], np.cumsum(d["ply_child_counts"])])
+    r_off = np.concatenate([[0], np.cumsum(d["game_records"])])
+    for gi in range(d["game_ruleset"].shape[0]):
+        training = int(d["game_training"][gi])
+        eng = trl.Engine(1, ruleset="s1" if d["game_ruleset"][gi] == 1 else "s2", seed=int(d["seed"]))
+        eng.reset(np.array([d["game_stream"][gi]], dtype=np.uint32))
+        s = StubSearch(eng, trl.mcts_config(max_iter=int(d["max_iter"]), training=training, save_all=int(not training),
+                                            auto_reset=0))
+        recs = _play_until_done(eng, s, 200 * 130)
+        mv = recs[recs["kind"] == trl.REC_MOVE]
+        mv = mv[np.argsort(mv["ply"], kind="stable")]
+        end = recs[recs["kind"] == trl.REC_GAME_END]
+        assert len(end) == 1 and len(mv) == d["game_plies"][gi]
+        game_data = [[], []]
+        for k in range(len(mv)):
+            fk = p_off[gi] + k
+            a, b = mv[k]["state"].copy(), d["ply_state"][fk].copy()
+            a[304:308] = 0; b[304:308] = 0
+            assert np.array_equal(a, b), "searched position, game %d ply %d" % (gi, k)
+            n = int(mv[k]["n_children"])
+            assert int(mv[k]["chosen"]) == d["ply_move"][fk]
+            assert int(mv[k]["saved"]) == (d["ply_save"][fk] or (not training))
+            assert np.array_equal(mv[k]["moves"][:n], d["ply_child_moves"][c_off[fk]:c_off[fk + 1]])
+            assert np.array_equal(mv[k]["visits"][:n].astype(np.int32), d["ply_child_visits"][c_off[fk]:c_off[fk + 1]])
+            if mv[k]["saved"]:
+                game_data[int(mv[k]["state"][312])] += records.records_for_move(mv[k]["state"], mv[k]["moves"][:n], mv[k]["visits"][:n])
+        data = records.finish_game(game_data, int(end[0]["winner"]))
+        want = d["rec_hash"][r_off[gi]:r_off[gi + 1]]
+        assert len(data) == len(want)
+        for i, rec in enumerate(data):
+            assert hashlib.sha256(json.dumps(rec, separators=(",", ":")).encode()).hexdigest() == str(want[i])
+
+
+def test_many_slots_match_oracle():
+    """96 concurrent games (mixed search lengths from playout-cap randomisation) played to the end on
+    the device == the oracle's play_game, game by game: plies, moves, winner."""
+    n, seed = 96, 4242
+    cfgk = dict(max_iter=24, training=1)
+    eng = trl.Engine(n, ruleset="s2", seed=seed)
+    eng.reset()
+    s = StubSearch(eng, trl.mcts_config(auto_reset=0, **cfgk))
+    recs = _play_until_done(eng, s, 60 * 250)
+    assert eng.mcts_stats()["overflow"] == 0
+    for g in range(0, n, 5):
+        o = op.play_game_stub(2, seed, g, op.default_mcts_config(**cfgk))
+        mine = recs[(recs["slot"] == g) & (recs["kind"] == trl.REC_MOVE)]
+        mine = mine[np.argsort(mine["ply"], kind="stable")]
+        end = recs[(recs["slot"] == g) & (recs["kind"] == trl.REC_GAME_END)]
+        assert len(mine) == o["plies"] and len(end) == 1
+        assert np.array_equal(mine["chosen"], o["ply_move"])
+        assert int(end[0]["winner"]) == o["winner"]
+        assert np.array_equal(end[0]["state"][:288], o["final"][:288])

@@ -3,7 +3,8 @@
 Import name: ``tetris_rl_amd`` (the directory name carries the reference's hyphenated
 repository name, so the repo root ships ``tetris_rl_amd.py`` which loads this package).
 """
-from .engine import Engine, EngineError, encode_move, decode_move, load_library, STATE_BYTES, MAX_LEGAL, MOVE_NONE  # noqa: F401
+from .engine import (Engine, EngineError, encode_move, decode_move, load_library, mcts_config,  # noqa: F401
+                     STATE_BYTES, MAX_LEGAL, MOVE_NONE, RECORD_DTYPE, REC_MOVE, REC_GAME_END)
 from . import build as _build_mod
 
 

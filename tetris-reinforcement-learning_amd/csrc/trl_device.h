@@ -133,7 +133,7 @@ __device__ __forceinline__ void emit_flagged(MgScratch &S, bool emit, int rot, i
 // hold / next (Player.create_piece must succeed, player.py:37-44).  Writes the encoded
 // placements of this piece type in ascending order to out[] and returns their number;
 // *overflow is set when a cap was hit.
-__device__ int movegen_wave(const uint16_t *rows, int type, bool need_spawn, MgScratch &S,
+static __device__ int movegen_wave(const uint16_t *rows, int type, bool need_spawn, MgScratch &S,
                             uint16_t *out, int out_cap, int lane, int *overflow) {
     // validity maps + clear planes
     for (int i = lane; i < 4 * MAP_H; i += 64) {
@@ -288,7 +288,7 @@ __device__ __forceinline__ void update_b2b_level(trl_player_state &p) {      // 
     p.b2b_level = (uint8_t)lvl;
 }
 // floor(q(1 + c/4)) style terms are evaluated as integer products over 4 or 8
-__device__ int get_attack(trl_player_state &p, int ruleset, int rows, bool tspin, bool mini, bool all_clear) {
+static __device__ int get_attack(trl_player_state &p, int ruleset, int rows, bool tspin, bool mini, bool all_clear) {
     int attack = 0;
     if (rows == 0) {
         p.combo = 0;
@@ -378,7 +378,7 @@ __device__ __forceinline__ bool garbage_push(trl_player_state &p, int col, int n
 }
 
 // Queue.generate_bag + Game.add_bag_to_all (piece_queue.py:17-21, game.py:34-38)
-__device__ void add_bag_to_all(trl_game_state &g, uint64_t seed) {
+static __device__ void add_bag_to_all(trl_game_state &g, uint64_t seed) {
     for (int i = 0; i < 2; i++) {
         uint64_t k = g.bag_ctr++;
         uint32_t bag = 0x6543210u;                       // nibble j = j
@@ -395,7 +395,7 @@ __device__ void add_bag_to_all(trl_game_state &g, uint64_t seed) {
 }
 
 // Game.setup (game.py:28-32) on a zeroed slot
-__device__ void game_setup(trl_game_state &g, int ruleset, uint64_t seed, uint32_t stream) {
+static __device__ void game_setup(trl_game_state &g, int ruleset, uint64_t seed, uint32_t stream) {
     uint64_t *w = reinterpret_cast<uint64_t *>(&g);
     for (int i = 0; i < (int)(sizeof(trl_game_state) / 8); i++) w[i] = 0;
     g.stream = stream; g.ruleset = (uint8_t)ruleset;
@@ -405,7 +405,10 @@ __device__ void game_setup(trl_game_state &g, int ruleset, uint64_t seed, uint32
 }
 
 // Game.make_move(move, add_bag, add_history=False)  (game.py:40-98, player.py:109-188)
-__device__ void make_move(trl_game_state &g, uint64_t seed, int move, bool add_bag) {
+// `gctr`: running garbage-draw counter to use instead of the state's own (search-time copies
+// draw from the real game's stream, as the reference draws from one global generator)
+static __device__ void make_move(trl_game_state &g, uint64_t seed, int move, bool add_bag, uint32_t *gctr = nullptr) {
+    uint32_t &garb_ctr = gctr ? *gctr : g.garb_ctr;
     trl_player_state &p = g.p[g.turn];
     trl_player_state &o = g.p[1 - g.turn];
     // Game.move_piece (game.py:40-64)
@@ -461,7 +464,7 @@ __device__ void make_move(trl_game_state &g, uint64_t seed, int move, bool add_b
     p.pieces += 1;
     // garbage_to_send = [column] * attack, then Game.check_garbage (game.py:100-117)
     int send = attack, column = 0;
-    if (attack > 0) column = (int)rng_below(seed, g.stream, TRL_RNG_GARBAGE, g.garb_ctr++, 10);
+    if (attack > 0) column = (int)rng_below(seed, g.stream, TRL_RNG_GARBAGE, garb_ctr++, 10);
     int cancel = send < (int)p.garbage_len ? send : (int)p.garbage_len;
     if (cancel > 0) { garbage_pop(p, cancel); send -= cancel; }
     if (p.garbage_len > 0 && cleared == 0) {                                    // spawn_garbage, board.py:12-21

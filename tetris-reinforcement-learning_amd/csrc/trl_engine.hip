@@ -10,8 +10,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <new>
-#include "../../include/tetris_engine.h"
-#include "trl_device.h"
+#include "trl_internal.h"
 
 using namespace trl;
 
@@ -19,65 +18,6 @@ static_assert(sizeof(trl_player_state) == 144, "trl_player_state layout");
 static_assert(sizeof(trl_game_state) == 320, "trl_game_state layout");
 
 namespace {
-
-constexpr int BLOCK = 128;
-constexpr int STATE_DW = sizeof(trl_game_state) / 4;    // 80
-
-struct BlockShared {
-    alignas(16) trl_game_state g;
-    MgScratch mg[2];
-    alignas(4) uint16_t list[2][TRL_MAX_LEGAL];
-    int cnt[2];
-    int order;          // which slot's list comes first in plane order
-    int overflow;
-    int chosen;         // rollout: encoded move picked for this ply (or -1)
-    int done;
-};
-
-__device__ __forceinline__ void load_state(BlockShared &sh, const trl_game_state *src, int tid) {
-    const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
-    uint32_t *d = reinterpret_cast<uint32_t *>(&sh.g);
-    if (tid < STATE_DW) d[tid] = s[tid];
-}
-__device__ __forceinline__ void store_state(const BlockShared &sh, trl_game_state *dst, int tid) {
-    const uint32_t *s = reinterpret_cast<const uint32_t *>(&sh.g);
-    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
-    if (tid < STATE_DW) d[tid] = s[tid];
-}
-
-// legal placements of the side to move into sh.list / sh.cnt; all 128 threads call it.
-// Returns (uniformly) the total count; list order = slot sh.order first.
-__device__ int block_movegen(BlockShared &sh, int tid) {
-    const int wave = tid >> 6, lane = tid & 63;
-    if (tid == 0) { sh.overflow = 0; sh.cnt[0] = 0; sh.cnt[1] = 0; sh.order = 0; }
-    __syncthreads();
-    const trl_game_state &g = sh.g;
-    bool live = !is_terminal(g) && !no_move(g);
-    if (live) {
-        const trl_player_state &p = g.p[g.turn];
-        int t0, t1;
-        movegen_types(p, &t0, &t1);
-        int type = wave == 0 ? t0 : t1;
-        if (type != P_NONE) {
-            int ovf = 0;
-            int n = movegen_wave(p.rows, type, wave == 1, sh.mg[wave], sh.list[wave], TRL_MAX_LEGAL, lane, &ovf);
-            if (lane == 0) { sh.cnt[wave] = n; if (ovf) sh.overflow = 1; }
-        }
-        if (tid == 0) {
-            // planes of different piece types are disjoint ranges: lower base first (argwhere order)
-            int b0 = t0 != P_NONE ? C_PLANE_BASE[t0] : 99, b1 = t1 != P_NONE ? C_PLANE_BASE[t1] : 99;
-            sh.order = b1 < b0 ? 1 : 0;
-        }
-    }
-    __syncthreads();
-    int total = sh.cnt[0] + sh.cnt[1];
-    if (total > TRL_MAX_LEGAL) { total = TRL_MAX_LEGAL; if (tid == 0) sh.overflow = 1; }
-    return total;
-}
-__device__ __forceinline__ uint16_t merged_move(const BlockShared &sh, int i) {
-    int a = sh.order, na = sh.cnt[a];
-    return i < na ? sh.list[a][i] : sh.list[1 - a][i - na];
-}
 
 // ---- kernels ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_reset(trl_game_state *states, const uint32_t *streams, int ruleset, uint64_t seed, int n) {
@@ -170,32 +110,11 @@ __global__ void k_attack_table(const int16_t *rows, int n, int16_t *out) {
 }  // namespace
 
 // ---- host side -----------------------------------------------------------------------------------
-struct trl_engine {
-    trl_config cfg;
-    hipStream_t stream;
-    bool own_stream;
-    trl_game_state *d_states;
-    uint16_t *d_counts, *d_moves, *d_in_moves;
-    unsigned long long *d_steps;
-    hipEvent_t ev0, ev1;
-    bool have_reset;
-    float last_ms;
-};
-
-static thread_local char g_err[512] = "";
-static int fail(int code, const char *fmt, const char *detail) {
-    snprintf(g_err, sizeof g_err, fmt, detail);
-    return code;
-}
-#define HIPCHK(call)                                                        \
-    do {                                                                    \
-        hipError_t e_ = (call);                                             \
-        if (e_ != hipSuccess) return fail(TRL_E_HIP, #call ": %s", hipGetErrorString(e_)); \
-    } while (0)
+thread_local char trl_g_err[512] = "";
 
 extern "C" {
 
-const char *trl_last_error(void) { return g_err; }
+const char *trl_last_error(void) { return trl_g_err; }
 const char *trl_version(void) { return "trl-hip 0.1 (gfx950)"; }
 
 int trl_engine_create(const trl_config *cfg, trl_engine **out) {
@@ -231,6 +150,7 @@ void trl_engine_destroy(trl_engine *h) {
     if (!h) return;
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
+    trl_mcts_free_internal(h);
     hipFree(h->d_states); hipFree(h->d_counts); hipFree(h->d_moves); hipFree(h->d_in_moves); hipFree(h->d_steps);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     if (h->own_stream) hipStreamDestroy(h->stream);

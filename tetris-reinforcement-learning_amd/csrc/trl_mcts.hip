@@ -1,0 +1,695 @@
+// trl_mcts.hip -- GPU-resident PUCT search + game driver (ai.py:299-659, 1570-1699), gfx950.
+//
+// One 128-thread workgroup per game slot and tick.  The tree of a slot lives in HBM as
+// structure-of-arrays node columns (children of a node are contiguous, so a selection step is
+// a coalesced scan of N / Q / P columns reduced by a block arg-max with the reference's
+// "last maximal child wins" rule); expanded positions live in a per-slot pool of 320-byte
+// states.  Selection, Game.copy + make_move, legal-move search and the net's input features
+// are one kernel (k_select); expansion, root noise, backup, FPU refresh and -- on the last
+// simulation of a search -- move choice, record, the real make_move and game turnover are the
+// other (k_expand).  The net runs between the two on the whole batch of leaves.
+//
+// Arithmetic mirrors the reference under numpy >= 2 (see oracle/tetris_oracle_mcts.c): float32
+// PUCT terms for float32-typed priors (nodes below the root), fp64 at the root and for value
+// sums.  This file must be compiled with -ffp-contract=off (no fused multiply-add: the
+// reference rounds after every operation).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <new>
+#include "trl_internal.h"
+
+using namespace trl;
+
+static_assert(sizeof(trl_record) == 2392, "trl_record layout");
+
+namespace {
+
+constexpr int DEFAULT_MAX_NODES = 65536;
+constexpr int DEFAULT_REC_CAP = 16384;
+
+struct SlotCtl {
+    int32_t phase;          // 0 = start a new search at the next select, 1 = searching, 2 = idle (game over, no auto-reset)
+    int32_t iter, max_iter, fast;
+    int32_t n_nodes, n_states;
+    int32_t leaf, leaf_kind, leaf_nlegal, leaf_state;
+    int32_t overflow, pad_;
+    double  terminal_value;
+};
+
+struct Tree {               // device pointers, column per node field; slot s owns [s * max_nodes, (s + 1) * max_nodes)
+    int32_t  *parent, *first, *visit, *state;
+    uint16_t *nchild, *move;
+    double   *wsum, *q, *prior;
+    uint8_t  *pf32, *turn;
+};
+
+struct DevMcts {
+    trl_mcts_config cfg;
+    int n_games, max_nodes, cap_states, rec_cap;
+    uint64_t seed;
+    Tree t;
+    SlotCtl *ctl;
+    trl_game_state *pool;       // [n_games][cap_states]
+    uint16_t *leaf_moves;       // [n_games][TRL_MAX_LEGAL]
+    trl_record *recs;
+    unsigned int *rec_count;
+    unsigned long long *counters;   // 0 simulations, 1 moves, 2 games, 3 dropped, 4 max nodes, 5 overflow
+};
+
+// ---- random draws of the search -----------------------------------------------------------------
+__device__ __forceinline__ double rng_unif(uint64_t seed, uint32_t stream, uint32_t purpose, uint64_t ctr) {
+    uint64_t k = mix64(seed ^ ((uint64_t)stream * 0xD1342543DE82EF95ull));
+    uint64_t u = mix64(k ^ ((uint64_t)purpose << 56) ^ ctr);
+    return ((double)(u >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+__device__ double gamma_draw(uint64_t seed, uint32_t stream, uint64_t base_ctr, double a) {
+    double d = (a + 1.0) - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (int attempt = 0; attempt < 64; attempt++) {
+        uint64_t cc = (base_ctr * 64 + (uint64_t)attempt) * 4;
+        double u1 = rng_unif(seed, stream, 5, cc), u2 = rng_unif(seed, stream, 5, cc + 1);
+        double x = sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        double u = rng_unif(seed, stream, 5, cc + 2);
+        if (log(u) < 0.5 * x * x + d - d * v + d * log(v)) {
+            double ub = rng_unif(seed, stream, 5, cc + 3);
+            return d * v * exp(log(ub) / a);
+        }
+    }
+    return 0.0;
+}
+// numpy's pairwise float64 sum (np.sum of a contiguous 1-D array, ai.py:600)
+__device__ double np_sum(const double *a, int n) {
+    if (n < 8) { double r = 0.0; for (int i = 0; i < n; i++) r += a[i]; return r; }
+    if (n <= 128) {
+        double r[8]; int i;
+        for (i = 0; i < 8; i++) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    int n2 = n / 2; n2 -= n2 % 8;
+    return np_sum(a, n2) + np_sum(a + n2, n - n2);       // depth <= 2 for n <= 512
+}
+
+// ---- shared memory of the two kernels ---------------------------------------------------------------
+struct SelectShared {
+    BlockShared b;
+    SlotCtl ctl;
+    double red_s[2]; int red_k[2];
+    int node;
+};
+struct ExpandShared {
+    alignas(16) trl_game_state g;
+    SlotCtl ctl;
+    float  pf[TRL_MAX_LEGAL];
+    double pd[TRL_MAX_LEGAL];
+    float  red_f[2];
+    double dsum;
+    int    flag, chosen, rec_idx, end_idx;
+};
+
+__device__ __forceinline__ void copy_state(trl_game_state *dst, const trl_game_state *src, int tid) {
+    const uint32_t *s = reinterpret_cast<const uint32_t *>(src);
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+    if (tid < STATE_DW) d[tid] = s[tid];
+}
+
+// ---- tick part A --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *real, float *grids, float *vec) {
+    __shared__ SelectShared sh;
+    const int tid = threadIdx.x, slot = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t nb = (size_t)slot * M.max_nodes;
+    trl_game_state *pool = M.pool + (size_t)slot * M.cap_states;
+    const trl_mcts_config &cfg = M.cfg;
+    if (tid == 0) sh.ctl = M.ctl[slot];
+    __syncthreads();
+    if (sh.ctl.phase == 2) {                       // idle slot: feed zeros to the net
+        for (int i = tid; i < 2 * TRL_GRID_FLOATS; i += BLOCK)
+            grids[((size_t)(i / TRL_GRID_FLOATS) * M.n_games + slot) * TRL_GRID_FLOATS + (i % TRL_GRID_FLOATS)] = 0.f;
+        for (int i = tid; i < TRL_VEC_FLOATS; i += BLOCK) vec[(size_t)slot * TRL_VEC_FLOATS + i] = 0.f;
+        return;
+    }
+    if (sh.ctl.phase == 0) {
+        // new search: root = game.copy() with previews restricted to 5 (ai.py:302-313)
+        copy_state(&sh.b.g, real + slot, tid);
+        __syncthreads();
+        if (tid == 0) {
+            trl_game_state &g = sh.b.g;
+            for (int i = 0; i < 2; i++)
+                if (g.p[i].queue_len > TRL_PREVIEWS) { g.p[i].queue_len = TRL_PREVIEWS; g.p[i].queue &= (1ull << (4 * TRL_PREVIEWS)) - 1; }
+            SlotCtl &c = sh.ctl;
+            c.fast = 0;
+            if (cfg.training && cfg.use_playout_cap) {                       // ai.py:322-330
+                double denom = cfg.playout_cap_chance * (cfg.playout_cap_mult - 1) + 1;
+                if (rng_unif(M.seed, g.stream, 3, g.ply) < cfg.playout_cap_chance)
+                    c.max_iter = (int)ceil(cfg.playout_cap_mult * (cfg.max_iter / denom));
+                else { c.max_iter = (int)floor(cfg.max_iter / denom); c.fast = 1; }
+            } else c.max_iter = cfg.max_iter;
+            c.iter = 0; c.n_nodes = 1; c.n_states = 1; c.phase = 1; c.overflow = 0;
+            M.t.parent[nb] = -1; M.t.first[nb] = -1; M.t.nchild[nb] = 0; M.t.move[nb] = TRL_MOVE_NONE;
+            M.t.visit[nb] = 0; M.t.wsum[nb] = 0.0; M.t.q[nb] = 0.0; M.t.prior[nb] = 0.0; M.t.state[nb] = 0;
+            M.t.pf32[nb] = 0; M.t.turn[nb] = g.turn;
+        }
+        __syncthreads();
+        copy_state(pool, &sh.b.g, tid);
+        __syncthreads();
+    }
+
+    // SELECT (ai.py:346-393): walk down by arg-max of Q + U, ties to the last child
+    int node = 0;
+    while (true) {
+        int n = M.t.nchild[nb + node];
+        if (n == 0) break;
+        const int first = M.t.first[nb + node];
+        const int parent_visits = M.t.visit[nb + node];
+        const double sqrt_parent = sqrt((double)parent_visits);
+        const double u_scale = cfg.cpuct * sqrt_parent / cfg.dpuct;
+        const bool check_forced = cfg.use_forced && cfg.training && node == 0 && !(cfg.use_playout_cap && sh.ctl.fast);
+        double best_s = -2.0; int best_k = -1;
+        for (int k = tid; k < n; k += BLOCK) {
+            const size_t ci = nb + first + k;
+            const int vc = M.t.visit[ci];
+            const double p = M.t.prior[ci], q = M.t.q[ci];
+            double s;
+            if (M.t.pf32[ci]) {                    // float32 expression (numpy weak-scalar promotion)
+                float pf = (float)p, U;
+                if (vc == 0) U = (float)u_scale * pf;
+                else U = (((float)cfg.cpuct * pf) * (float)sqrt_parent) / (float)(cfg.dpuct + vc);
+                s = (double)((float)q + U);
+            } else {
+                double U;
+                if (vc == 0) U = u_scale * p;
+                else U = cfg.cpuct * p * sqrt_parent / (cfg.dpuct + vc);
+                s = q + U;
+            }
+            if (check_forced && vc >= 1) {         // ai.py:377-381
+                double n_forced = sqrt(cfg.c_forced * p * parent_visits);
+                if (vc < n_forced) s = INFINITY;
+            }
+            if (s >= best_s) { best_s = s; best_k = k; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            double os = __shfl_down(best_s, d, 64); int ok = __shfl_down(best_k, d, 64);
+            if (os > best_s || (os == best_s && ok > best_k)) { best_s = os; best_k = ok; }
+        }
+        if (lane == 0) { sh.red_s[wave] = best_s; sh.red_k[wave] = best_k; }
+        __syncthreads();
+        if (tid == 0) {
+            int k = sh.red_k[0]; double s = sh.red_s[0];
+            if (sh.red_s[1] > s || (sh.red_s[1] == s && sh.red_k[1] > k)) k = sh.red_k[1];
+            sh.node = first + k;
+        }
+        __syncthreads();
+        node = sh.node;
+        __syncthreads();
+    }
+
+    // STEP (ai.py:398-403): node.game = parent.game.copy(); make_move(move, add_bag=False)
+    int sidx;
+    if (node != 0) {
+        const int par = M.t.parent[nb + node];
+        copy_state(&sh.b.g, pool + M.t.state[nb + par], tid);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t gctr = real[slot].garb_ctr;               // the reference draws from one global stream
+            make_move(sh.b.g, M.seed, M.t.move[nb + node], false, &gctr);
+            real[slot].garb_ctr = gctr;
+            int s = M.t.state[nb + node];
+            if (s < 0) { s = sh.ctl.n_states++; M.t.state[nb + node] = s; }
+            M.t.turn[nb + node] = sh.b.g.turn;
+            sh.ctl.leaf_state = s;
+        }
+        __syncthreads();
+        sidx = sh.ctl.leaf_state;
+        copy_state(pool + sidx, &sh.b.g, tid);
+    } else {
+        copy_state(&sh.b.g, pool, tid);
+        sidx = 0;
+        __syncthreads();
+    }
+
+    // leaf kind + legal moves (ai.py:406-417, 472-479)
+    const trl_game_state &g = sh.b.g;
+    int kind, nlegal = 0;
+    if (is_terminal(g)) kind = 2;
+    else if (no_move(g)) kind = 1;
+    else {
+        kind = 0;
+        nlegal = block_movegen(sh.b, tid);
+        for (int i = tid; i < nlegal; i += BLOCK) M.leaf_moves[(size_t)slot * TRL_MAX_LEGAL + i] = merged_move(sh.b, i);
+    }
+
+    // game_to_X (ai.py:1364-1413): side to move first
+    {
+        const trl_player_state &a = g.p[g.turn], &o = g.p[1 - g.turn];
+        for (int i = tid; i < 2 * TRL_GRID_FLOATS; i += BLOCK) {
+            int who = i / TRL_GRID_FLOATS, cell = i - who * TRL_GRID_FLOATS;
+            const trl_player_state &p = who ? o : a;
+            int r = cell / TRL_COLS, c = cell - r * TRL_COLS;
+            grids[((size_t)who * M.n_games + slot) * TRL_GRID_FLOATS + cell] = (float)((p.rows[r] >> c) & 1);
+        }
+        float *v = vec + (size_t)slot * TRL_VEC_FLOATS;
+        for (int i = tid; i < TRL_VEC_FLOATS; i += BLOCK) {
+            float x;
+            if (i == 104) x = (float)g.turn;                                  // color of the side to move
+            else {
+                const trl_player_state &p = (i < 52) ? a : o;
+                int j = (i < 52) ? i : i - 52;
+                if (j < 49) {                                                 // pieces one-hot [7][7]
+                    int row = j / 7, col = j - row * 7;
+                    int pc = row == 0 ? (int)p.piece : row == 1 ? (int)p.held
+                           : ((row - 2) < (int)p.queue_len ? (int)((p.queue >> (4 * (row - 2))) & 15) : P_NONE);
+                    x = (pc == col) ? 1.f : 0.f;
+                } else x = (j == 49) ? (float)p.b2b : (j == 50) ? (float)p.combo : (float)p.garbage_len;
+            }
+            v[i] = x;
+        }
+    }
+
+    if (tid == 0) {
+        SlotCtl &c = sh.ctl;
+        c.iter += 1;
+        c.leaf = node; c.leaf_kind = kind; c.leaf_nlegal = nlegal; c.leaf_state = sidx;
+        if (kind == 2) {
+            int w = g.p[0].game_over ? 1 : (g.p[1].game_over ? 0 : -1);      // Game.winner, game.py:217-225
+            c.terminal_value = (w == g.turn) ? 1.0 : (w == 1 - g.turn) ? 0.0 : 0.5;
+        }
+        if (sh.b.overflow) c.overflow = 1;
+        M.ctl[slot] = c;
+        atomicAdd(&M.counters[0], 1ull);
+    }
+}
+
+// ---- tick part B --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *real, const float *values, const float *policy) {
+    __shared__ ExpandShared sh;
+    const int tid = threadIdx.x, slot = blockIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t nb = (size_t)slot * M.max_nodes;
+    trl_game_state *pool = M.pool + (size_t)slot * M.cap_states;
+    const trl_mcts_config &cfg = M.cfg;
+    if (tid == 0) sh.ctl = M.ctl[slot];
+    __syncthreads();
+    if (sh.ctl.phase != 1) return;
+    const int leaf = sh.ctl.leaf, kind = sh.ctl.leaf_kind;
+    const double value_min = 0.0;
+    double value = (kind == 2) ? sh.ctl.terminal_value : (double)values[slot];
+
+    // EXPAND (ai.py:411-458)
+    if (kind == 0) {
+        int n = sh.ctl.leaf_nlegal;
+        const int first = sh.ctl.n_nodes;
+        if (first + n > M.max_nodes) { n = 0; if (tid == 0) { sh.ctl.overflow = 1; atomicAdd(&M.counters[5], 1ull); } }
+        const uint16_t *lm = M.leaf_moves + (size_t)slot * TRL_MAX_LEGAL;
+        const float *pol = policy + (size_t)slot * TRL_POLICY_SIZE;
+        float mymax = 0.f;
+        for (int k = tid; k < n; k += BLOCK) {
+            int m = lm[k];
+            float p = pol[(TRL_MOVE_PLANE(m) * TRL_POLICY_ROWS + TRL_MOVE_ROW(m)) * TRL_POLICY_COLS + TRL_MOVE_COL(m)];
+            if (p <= 0.f) p = 1e-25f;                                          // ai.py:411
+            sh.pf[k] = p;
+            mymax = fmaxf(mymax, p);
+        }
+        const bool root_soft = (leaf == 0) && cfg.use_root_softmax;
+        if (root_soft) {                                                       // ai.py:428-434
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mymax = fmaxf(mymax, __shfl_down(mymax, d, 64));
+            if (lane == 0) sh.red_f[wave] = mymax;
+            __syncthreads();
+            const double log_max = log((double)fmaxf(sh.red_f[0], sh.red_f[1]));
+            const double inv_temp = 1.0 / cfg.root_softmax_temp;
+            for (int k = tid; k < n; k += BLOCK) sh.pd[k] = exp((log((double)sh.pf[k]) - log_max) * inv_temp);
+        }
+        __syncthreads();
+        if (tid == 0) {                                                        // sum(policies), in list order
+            if (root_soft) { double s = 0.0; for (int k = 0; k < n; k++) s += sh.pd[k]; sh.dsum = s; }
+            else { float s = 0.f; for (int k = 0; k < n; k++) s = s + sh.pf[k]; sh.red_f[0] = s; }
+        }
+        __syncthreads();
+        const double q0 = cfg.fpu_reduction ? fmax(value_min, 1.0 - value) : fmax(value_min, cfg.fpu_value);   // ai.py:447-453
+        const double dsum = root_soft ? sh.dsum : 0.0;
+        const float fsum = sh.red_f[0];
+        for (int k = tid; k < n; k += BLOCK) {
+            const size_t ci = nb + first + k;
+            M.t.parent[ci] = leaf; M.t.first[ci] = -1; M.t.nchild[ci] = 0; M.t.move[ci] = lm[k];
+            M.t.visit[ci] = 0; M.t.wsum[ci] = 0.0; M.t.q[ci] = q0; M.t.state[ci] = -1; M.t.turn[ci] = 0;
+            if (root_soft) { M.t.prior[ci] = sh.pd[k] / dsum; M.t.pf32[ci] = 0; }
+            else { M.t.prior[ci] = (double)(sh.pf[k] / fsum); M.t.pf32[ci] = 1; }
+        }
+        if (tid == 0 && n > 0) {
+            M.t.first[nb + leaf] = first; M.t.nchild[nb + leaf] = (uint16_t)n;
+            sh.ctl.n_nodes = first + n;
+            atomicMax(&M.counters[4], (unsigned long long)(first + n));
+        }
+        __syncthreads();
+    }
+
+    // NOISE (ai.py:482-499): un-normalised gamma draws on the root's children
+    if (cfg.training && !sh.ctl.fast && cfg.use_dirichlet && leaf == 0) {
+        const int n = M.t.nchild[nb], first = M.t.first[nb];
+        if (n > 0) {
+            double a = cfg.dir_alpha;
+            if (cfg.use_dir_s) a *= cfg.dir_s / n;
+            const uint32_t stream = real[slot].stream, ply = real[slot].ply;
+            for (int k = tid; k < n; k += BLOCK) {
+                const size_t ci = nb + first + k;
+                double noise = gamma_draw(M.seed, stream, (uint64_t)ply * 512 + (uint64_t)k, a);
+                double p = M.t.prior[ci];
+                if (M.t.pf32[ci]) p = (double)((float)p * (float)(1 - cfg.dir_expl)) + noise * cfg.dir_expl;
+                else p = p * (1 - cfg.dir_expl) + noise * cfg.dir_expl;
+                M.t.prior[ci] = p; M.t.pf32[ci] = 0;
+            }
+        }
+        __syncthreads();
+    }
+
+    // BACKUP (ai.py:504-533) and FPU refresh of the unvisited siblings (ai.py:536-565)
+    if (tid == 0) {
+        value = 1.0 - value;
+        const double pos = value, neg = 1.0 - value;
+        const int final_turn = M.t.turn[nb + leaf];
+        for (int n = leaf;; n = M.t.parent[nb + n]) {
+            const size_t i = nb + n;
+            int vc = M.t.visit[i] + 1;
+            double w = M.t.wsum[i] + ((M.t.turn[i] == final_turn) ? pos : neg);
+            M.t.visit[i] = vc; M.t.wsum[i] = w; M.t.q[i] = w / vc;
+            if (n == 0) break;
+        }
+        sh.flag = 0;
+        if (leaf != 0 && cfg.fpu_reduction) {
+            const int par = M.t.parent[nb + leaf];
+            if (par != 0) {
+                const int n = M.t.nchild[nb + par], first = M.t.first[nb + par];
+                float explored = 0.f; bool any = false;
+                for (int k = 0; k < n; k++)
+                    if (M.t.visit[nb + first + k] > 0) {
+                        float p = (float)M.t.prior[nb + first + k];
+                        explored = any ? explored + p : p; any = true;
+                    }
+                double fpu = (1.0 - M.t.q[nb + par]) - cfg.fpu_value * sqrt((double)explored);
+                if (!(fpu > value_min)) fpu = value_min;
+                sh.pd[0] = fpu; sh.flag = 1; sh.chosen = par;
+            }
+        }
+    }
+    __syncthreads();
+    if (sh.flag) {
+        const int par = sh.chosen, n = M.t.nchild[nb + par], first = M.t.first[nb + par];
+        const double fpu = sh.pd[0];
+        for (int k = tid; k < n; k += BLOCK)
+            if (M.t.visit[nb + first + k] == 0) M.t.q[nb + first + k] = fpu;
+    }
+    __syncthreads();
+
+    // end of the search: choose, record, play (ai.py:568-614, 1610-1695)
+    if (sh.ctl.iter >= sh.ctl.max_iter) {
+        const int n = M.t.nchild[nb], first = M.t.first[nb];
+        copy_state(&sh.g, real + slot, tid);
+        for (int k = tid; k < n; k += BLOCK) sh.pd[k] = (double)M.t.visit[nb + first + k];
+        __syncthreads();
+        if (tid == 0) {
+            int sel = 0;
+            const double temp = cfg.training ? cfg.temperature : 0.0;
+            if (n > 0) {
+                if (temp == 0.0) {                                             // np.argmax: first maximum
+                    double best = -1.0;
+                    for (int k = 0; k < n; k++) if (sh.pd[k] > best) { best = sh.pd[k]; sel = k; }
+                } else {                                                       // N^(1/T), normalise, random.choices
+                    for (int k = 0; k < n; k++) sh.pd[k] = pow(sh.pd[k], 1.0 / temp);
+                    double s = np_sum(sh.pd, n);
+                    double acc = 0.0;
+                    for (int k = 0; k < n; k++) { double pr = sh.pd[k] / s; acc = (k == 0) ? pr : acc + pr; sh.pd[k] = acc; }
+                    double total = sh.pd[n - 1] + 0.0;
+                    double x = rng_unif(M.seed, sh.g.stream, 4, sh.g.ply) * total;
+                    int lo = 0, hi = n - 1;
+                    while (lo < hi) { int mid = (lo + hi) / 2; if (x < sh.pd[mid]) hi = mid; else lo = mid + 1; }
+                    sel = lo;
+                }
+            }
+            sh.chosen = n > 0 ? (int)M.t.move[nb + first + sel] : -1;
+            unsigned int idx = atomicAdd(M.rec_count, 1u);
+            sh.rec_idx = idx < (unsigned)M.rec_cap ? (int)idx : -1;
+            if (sh.rec_idx < 0) atomicAdd(&M.counters[3], 1ull);
+        }
+        __syncthreads();
+        if (sh.rec_idx >= 0) {                                                 // the position searched + (move, N) of the root children
+            trl_record *r = M.recs + sh.rec_idx;
+            copy_state(&r->state, &sh.g, tid);
+            for (int k = tid; k < TRL_MAX_LEGAL; k += BLOCK) {
+                r->moves[k] = k < n ? M.t.move[nb + first + k] : (uint16_t)0;
+                r->visits[k] = k < n ? (uint16_t)M.t.visit[nb + first + k] : (uint16_t)0;
+            }
+            if (tid == 0) {
+                r->slot = slot; r->episode = sh.g.episode; r->ply = sh.g.ply; r->n_children = (uint16_t)n;
+                r->kind = TRL_REC_MOVE; r->winner = -1; r->chosen = (uint16_t)sh.chosen;
+                r->saved = (uint8_t)((!sh.ctl.fast) || cfg.save_all); r->pad_ = 0;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            trl_game_state &g = sh.g;
+            bool over = true;
+            if (sh.chosen >= 0) {
+                make_move(g, M.seed, sh.chosen, true);                        // game.make_move(move), ai.py:1668
+                // while not terminal and len(history.states) < MAX_MOVES  (history: 1 + player-1 placements)
+                over = is_terminal(g) || (1 + g.p[1].pieces) >= TRL_MAX_MOVES;
+            }
+            atomicAdd(&M.counters[1], 1ull);
+            sh.end_idx = -1; sh.flag = over ? 1 : 0;
+            if (over) {
+                unsigned int idx = atomicAdd(M.rec_count, 1u);
+                if (idx < (unsigned)M.rec_cap) sh.end_idx = (int)idx; else atomicAdd(&M.counters[3], 1ull);
+                atomicAdd(&M.counters[2], 1ull);
+            }
+        }
+        __syncthreads();
+        if (sh.flag) {
+            if (sh.end_idx >= 0) {
+                trl_record *r = M.recs + sh.end_idx;
+                copy_state(&r->state, &sh.g, tid);
+                if (tid == 0) {
+                    const trl_game_state &g = sh.g;
+                    r->slot = slot; r->episode = g.episode; r->ply = g.ply; r->n_children = 0; r->kind = TRL_REC_GAME_END;
+                    r->winner = (int8_t)(g.p[0].game_over ? 1 : (g.p[1].game_over ? 0 : -1));
+                    r->chosen = 0; r->saved = 0; r->pad_ = 0;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                if (cfg.auto_reset) {
+                    trl_game_state &g = sh.g;
+                    uint32_t stream = g.stream + 0x01000000u, episode = g.episode + 1;
+                    int ruleset = g.ruleset; uint8_t flags = g.flags;
+                    game_setup(g, ruleset, M.seed, stream);
+                    g.episode = episode; g.flags = flags;
+                    sh.ctl.phase = 0;
+                } else sh.ctl.phase = 2;
+            }
+        } else if (tid == 0) sh.ctl.phase = 0;
+        __syncthreads();
+        copy_state(real + slot, &sh.g, tid);
+    }
+    if (tid == 0) M.ctl[slot] = sh.ctl;
+}
+
+// gather of the current leaf states (tests / host-side evaluators)
+__global__ void k_leaf_gather(DevMcts M, trl_game_state *out, int32_t *info) {
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    const SlotCtl c = M.ctl[slot];
+    copy_state(out + slot, M.pool + (size_t)slot * M.cap_states + (c.phase == 1 ? c.leaf_state : 0), tid);
+    if (tid == 0) { info[4 * slot] = c.iter; info[4 * slot + 1] = c.max_iter; info[4 * slot + 2] = c.phase == 1 ? c.leaf_kind : 3; info[4 * slot + 3] = c.leaf_nlegal; }
+}
+__global__ void k_root_children(DevMcts M, int32_t *counts, uint16_t *moves, int32_t *visits, double *q, double *p) {
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    const size_t nb = (size_t)slot * M.max_nodes;
+    const int n = M.t.nchild[nb], first = M.t.first[nb];
+    if (tid == 0) counts[slot] = n;
+    for (int k = tid; k < n; k += blockDim.x) {
+        size_t o = (size_t)slot * TRL_MAX_LEGAL + k, ci = nb + first + k;
+        moves[o] = M.t.move[ci]; visits[o] = M.t.visit[ci]; q[o] = M.t.q[ci]; p[o] = M.t.prior[ci];
+    }
+}
+
+// deterministic stub evaluator (tests): same function as oracle/tetris_oracle_mcts.c to_stub_eval_state
+__global__ __launch_bounds__(256) void k_stub_eval(DevMcts M, float *values, float *policy) {
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    const SlotCtl c = M.ctl[slot];
+    const trl_game_state *s = M.pool + (size_t)slot * M.cap_states + (c.phase == 1 ? c.leaf_state : 0);
+    uint64_t h = 0x243F6A8885A308D3ull;
+    for (int i = 0; i < 2; i++) {
+        const uint64_t *w = reinterpret_cast<const uint64_t *>(&s->p[i]);
+        for (int k = 0; k < 15; k++) h = mix64(h ^ w[k]);
+        const trl_player_state &p = s->p[i];
+        uint64_t meta = (uint64_t)(uint16_t)p.b2b | ((uint64_t)(uint16_t)p.combo << 16) | ((uint64_t)p.b2b_level << 32)
+                      | ((uint64_t)p.piece << 40) | ((uint64_t)p.held << 44) | ((uint64_t)p.queue_len << 48)
+                      | ((uint64_t)p.garbage_len << 53) | ((uint64_t)p.game_over << 60);
+        h = mix64(h ^ meta);
+    }
+    h = mix64(h ^ s->turn);
+    if (tid == 0) values[slot] = (float)(mix64(h) >> 40) * (1.0f / 16777216.0f);
+    for (int i = tid; i < TRL_POLICY_SIZE; i += blockDim.x) {
+        uint64_t k = mix64(h ^ ((uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull));
+        float u = (float)(k >> 40) * (1.0f / 16777216.0f);
+        policy[(size_t)slot * TRL_POLICY_SIZE + i] = (k & 15) == 0 ? 0.0f : u * u;
+    }
+}
+
+}  // namespace
+
+// ---- host side -----------------------------------------------------------------------------------------
+struct trl_mcts {
+    DevMcts d;
+    uint64_t ticks;
+    trl_game_state *d_leaf_tmp;
+    int32_t *d_info_tmp;
+    void *d_root_tmp;
+};
+
+static void free_dev(DevMcts &d) {
+    hipFree(d.t.parent); hipFree(d.t.first); hipFree(d.t.visit); hipFree(d.t.state); hipFree(d.t.nchild); hipFree(d.t.move);
+    hipFree(d.t.wsum); hipFree(d.t.q); hipFree(d.t.prior); hipFree(d.t.pf32); hipFree(d.t.turn);
+    hipFree(d.ctl); hipFree(d.pool); hipFree(d.leaf_moves); hipFree(d.recs); hipFree(d.rec_count); hipFree(d.counters);
+}
+
+void trl_mcts_free_internal(trl_engine *h) {
+    if (!h || !h->mcts) return;
+    free_dev(h->mcts->d);
+    hipFree(h->mcts->d_leaf_tmp); hipFree(h->mcts->d_info_tmp); hipFree(h->mcts->d_root_tmp);
+    delete h->mcts;
+    h->mcts = nullptr;
+}
+
+extern "C" {
+
+int trl_mcts_create(trl_engine *h, const trl_mcts_config *cfg) {
+    if (!h || !cfg || cfg->max_iter <= 0) return fail(TRL_E_INVALID, "trl_mcts_create: %s", "bad argument");
+    if (!h->have_reset) return fail(TRL_E_STATE, "%s", "trl_mcts_create before trl_env_reset / trl_env_set_state");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    trl_mcts_free_internal(h);
+    trl_mcts *m = new (std::nothrow) trl_mcts();
+    if (!m) return fail(TRL_E_INVALID, "%s", "out of host memory");
+    memset(m, 0, sizeof *m);
+    DevMcts &d = m->d;
+    d.cfg = *cfg;
+    d.n_games = h->cfg.n_games;
+    d.seed = h->cfg.seed;
+    d.max_nodes = cfg->max_nodes > 0 ? cfg->max_nodes : DEFAULT_MAX_NODES;
+    d.rec_cap = cfg->record_capacity > 0 ? cfg->record_capacity : DEFAULT_REC_CAP;
+    int longest = cfg->max_iter;
+    if (cfg->training && cfg->use_playout_cap) {
+        double denom = cfg->playout_cap_chance * (cfg->playout_cap_mult - 1) + 1;
+        longest = (int)ceil(cfg->playout_cap_mult * (cfg->max_iter / denom));
+        if (longest < cfg->max_iter) longest = cfg->max_iter;
+    }
+    d.cap_states = longest + 2;
+    size_t nn = (size_t)d.n_games * d.max_nodes, n = (size_t)d.n_games;
+    HIPCHK(hipMalloc(&d.t.parent, nn * 4)); HIPCHK(hipMalloc(&d.t.first, nn * 4)); HIPCHK(hipMalloc(&d.t.visit, nn * 4));
+    HIPCHK(hipMalloc(&d.t.state, nn * 4)); HIPCHK(hipMalloc(&d.t.nchild, nn * 2)); HIPCHK(hipMalloc(&d.t.move, nn * 2));
+    HIPCHK(hipMalloc(&d.t.wsum, nn * 8)); HIPCHK(hipMalloc(&d.t.q, nn * 8)); HIPCHK(hipMalloc(&d.t.prior, nn * 8));
+    HIPCHK(hipMalloc(&d.t.pf32, nn)); HIPCHK(hipMalloc(&d.t.turn, nn));
+    HIPCHK(hipMalloc(&d.ctl, n * sizeof(SlotCtl)));
+    HIPCHK(hipMalloc(&d.pool, n * d.cap_states * sizeof(trl_game_state)));
+    HIPCHK(hipMalloc(&d.leaf_moves, n * TRL_MAX_LEGAL * 2));
+    HIPCHK(hipMalloc(&d.recs, (size_t)d.rec_cap * sizeof(trl_record)));
+    HIPCHK(hipMalloc(&d.rec_count, 4));
+    HIPCHK(hipMalloc(&d.counters, 8 * 8));
+    HIPCHK(hipMalloc(&m->d_leaf_tmp, n * sizeof(trl_game_state)));
+    HIPCHK(hipMalloc(&m->d_info_tmp, n * 16));
+    HIPCHK(hipMalloc(&m->d_root_tmp, n * (4 + TRL_MAX_LEGAL * (2 + 4 + 8 + 8))));
+    HIPCHK(hipMemsetAsync(d.ctl, 0, n * sizeof(SlotCtl), h->stream));            // phase 0: start a search
+    HIPCHK(hipMemsetAsync(d.t.nchild, 0, nn * 2, h->stream));
+    HIPCHK(hipMemsetAsync(d.rec_count, 0, 4, h->stream));
+    HIPCHK(hipMemsetAsync(d.counters, 0, 64, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->mcts = m;
+    return TRL_OK;
+}
+
+int trl_mcts_select(trl_engine *h, float *dev_grids, float *dev_vec) {
+    if (!h || !h->mcts || !dev_grids || !dev_vec) return fail(TRL_E_INVALID, "trl_mcts_select: %s", "null argument / no search attached");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_select, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_grids, dev_vec);
+    HIPCHK(hipGetLastError());
+    return TRL_OK;
+}
+
+int trl_mcts_expand(trl_engine *h, const float *dev_values, const float *dev_policy) {
+    if (!h || !h->mcts || !dev_values || !dev_policy) return fail(TRL_E_INVALID, "trl_mcts_expand: %s", "null argument / no search attached");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_expand, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_values, dev_policy);
+    HIPCHK(hipGetLastError());
+    h->mcts->ticks++;
+    return TRL_OK;
+}
+
+int trl_mcts_drain_records(trl_engine *h, trl_record *host_out, int cap, int *n_out) {
+    if (!h || !h->mcts || !host_out || !n_out || cap < 0) return fail(TRL_E_INVALID, "trl_mcts_drain_records: %s", "bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    DevMcts &d = h->mcts->d;
+    unsigned int cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, d.rec_count, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (cnt > (unsigned)d.rec_cap) cnt = (unsigned)d.rec_cap;
+    if ((int)cnt > cap) return fail(TRL_E_OVERFLOW, "trl_mcts_drain_records: %s", "host buffer smaller than the pending records");
+    if (cnt) HIPCHK(hipMemcpyAsync(host_out, d.recs, (size_t)cnt * sizeof(trl_record), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemsetAsync(d.rec_count, 0, 4, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    *n_out = (int)cnt;
+    return TRL_OK;
+}
+
+int trl_mcts_get_stats(trl_engine *h, trl_mcts_stats *out) {
+    if (!h || !h->mcts || !out) return fail(TRL_E_INVALID, "trl_mcts_get_stats: %s", "bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    unsigned long long c[8];
+    HIPCHK(hipMemcpyAsync(c, h->mcts->d.counters, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    out->ticks = h->mcts->ticks; out->simulations = c[0]; out->moves = c[1]; out->games = c[2];
+    out->records_dropped = c[3]; out->max_nodes_used = (uint32_t)c[4]; out->overflow = (uint32_t)c[5];
+    return TRL_OK;
+}
+
+int trl_mcts_leaf_states(trl_engine *h, trl_game_state *host_out, int32_t *host_info) {
+    if (!h || !h->mcts || !host_out || !host_info) return fail(TRL_E_INVALID, "trl_mcts_leaf_states: %s", "bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    int n = h->cfg.n_games;
+    hipLaunchKernelGGL(k_leaf_gather, dim3(n), dim3(128), 0, h->stream, h->mcts->d, h->mcts->d_leaf_tmp, h->mcts->d_info_tmp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host_out, h->mcts->d_leaf_tmp, (size_t)n * sizeof(trl_game_state), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(host_info, h->mcts->d_info_tmp, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return TRL_OK;
+}
+
+int trl_mcts_root_children(trl_engine *h, int32_t *counts, uint16_t *moves, int32_t *visits, double *q, double *p) {
+    if (!h || !h->mcts || !counts || !moves || !visits || !q || !p) return fail(TRL_E_INVALID, "trl_mcts_root_children: %s", "bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    size_t n = (size_t)h->cfg.n_games, L = TRL_MAX_LEGAL;
+    char *base = (char *)h->mcts->d_root_tmp;
+    double *dq = (double *)base, *dp = dq + n * L;
+    int32_t *dv = (int32_t *)(dp + n * L), *dc = dv + n * L;
+    uint16_t *dm = (uint16_t *)(dc + n);
+    hipLaunchKernelGGL(k_root_children, dim3((unsigned)n), dim3(128), 0, h->stream, h->mcts->d, dc, dm, dv, dq, dp);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(counts, dc, n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(moves, dm, n * L * 2, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(visits, dv, n * L * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(q, dq, n * L * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(p, dp, n * L * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return TRL_OK;
+}
+
+// test hook: the stub evaluator on the current leaves (values[n], policy[n][11583], device pointers)
+int trl_debug_stub_eval(trl_engine *h, float *dev_values, float *dev_policy) {
+    if (!h || !h->mcts) return fail(TRL_E_INVALID, "%s", "no search attached");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_stub_eval, dim3(h->cfg.n_games), dim3(256), 0, h->stream, h->mcts->d, dev_values, dev_policy);
+    HIPCHK(hipGetLastError());
+    return TRL_OK;
+}
+
+}  // extern "C"

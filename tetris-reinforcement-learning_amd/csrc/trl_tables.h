@@ -12,7 +12,7 @@ enum : int { PZ = 0, PL = 1, PO = 2, PS = 3, PI = 4, PJ = 5, PT = 6, P_NONE = 7 
 constexpr uint16_t mp(int x0, int y0, int x1, int y1, int x2, int y2, int x3, int y3) {
     return (uint16_t)((x0 | (y0 << 2)) | ((x1 | (y1 << 2)) << 4) | ((x2 | (y2 << 2)) << 8) | ((x3 | (y3 << 2)) << 12));
 }
-__device__ __constant__ const uint16_t C_MINO[7 * 4] = {
+static __device__ __constant__ const uint16_t C_MINO[7 * 4] = {
     /* Z */ mp(0,0,1,0,1,1,2,1), mp(1,1,1,2,2,0,2,1), mp(0,1,1,1,1,2,2,2), mp(0,1,0,2,1,0,1,1),
     /* L */ mp(0,1,1,1,2,0,2,1), mp(1,0,1,1,1,2,2,2), mp(0,1,0,2,1,1,2,1), mp(0,0,1,0,1,1,1,2),
     /* O */ mp(0,0,0,1,1,0,1,1), mp(0,0,0,1,1,0,1,1), mp(0,0,0,1,1,0,1,1), mp(0,0,0,1,1,0,1,1),
@@ -31,7 +31,7 @@ constexpr uint64_t kk(int n, int x0 = 0, int y0 = 0, int x1 = 0, int y1 = 0, int
          | ((uint64_t)((x4 + 2) | ((y4 + 2) << 3)) << 24) | ((uint64_t)((x5 + 2) | ((y5 + 2) << 3)) << 30);
 }
 // index [(isI * 4 + from) * 3 + (dir - 1)], to = (from + dir) % 4
-__device__ __constant__ const uint64_t C_KICK[2 * 4 * 3] = {
+static __device__ __constant__ const uint64_t C_KICK[2 * 4 * 3] = {
     // wallkicks (all pieces but I)
     /* 0->1 */ kk(5, 0,0, -1,0, -1,1, 0,-2, -1,-2),
     /* 0->2 */ kk(6, 0,0, 0,1, 1,1, -1,1, 1,0, -1,0),
@@ -63,7 +63,7 @@ __device__ __constant__ const uint64_t C_KICK[2 * 4 * 3] = {
 // ---- policy planes (const.py:82-136) ------------------------------------------------------------
 // plane -> type | rot << 3 | tspin << 5
 constexpr uint8_t pp(int t, int r, int s) { return (uint8_t)(t | (r << 3) | (s << 5)); }
-__device__ __constant__ const uint8_t C_PLANE[27] = {
+static __device__ __constant__ const uint8_t C_PLANE[27] = {
     pp(PO,0,0),
     pp(PZ,0,0), pp(PZ,1,0), pp(PS,0,0), pp(PS,1,0), pp(PI,0,0), pp(PI,1,0),
     pp(PL,0,0), pp(PL,1,0), pp(PL,2,0), pp(PL,3,0), pp(PJ,0,0), pp(PJ,1,0), pp(PJ,2,0), pp(PJ,3,0),
@@ -71,8 +71,8 @@ __device__ __constant__ const uint8_t C_PLANE[27] = {
     pp(PT,0,2), pp(PT,1,2), pp(PT,2,2), pp(PT,3,2),
 };
 // first plane / number of distinct rotations / bounding-box height (len(piece_dict[type])) per type
-__device__ __constant__ const uint8_t C_PLANE_BASE[7] = {1, 7, 0, 3, 5, 11, 15};
-__device__ __constant__ const uint8_t C_NROT[7]       = {2, 4, 1, 2, 2, 4, 4};
-__device__ __constant__ const uint8_t C_BOX[7]        = {3, 3, 2, 3, 4, 3, 3};
+static __device__ __constant__ const uint8_t C_PLANE_BASE[7] = {1, 7, 0, 3, 5, 11, 15};
+static __device__ __constant__ const uint8_t C_NROT[7]       = {2, 4, 1, 2, 2, 4, 4};
+static __device__ __constant__ const uint8_t C_BOX[7]        = {3, 3, 2, 3, 4, 3, 3};
 
 }  // namespace trl

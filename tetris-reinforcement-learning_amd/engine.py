@@ -21,7 +21,51 @@ ABI_SYMBOLS = [
     "trl_env_reset", "trl_env_get_state", "trl_env_set_state", "trl_env_state_dev",
     "trl_env_legal_moves", "trl_env_legal_dev", "trl_env_step", "trl_env_step_dev",
     "trl_env_rollout_random", "trl_last_kernel_ms",
+    "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_drain_records", "trl_mcts_get_stats",
+    "trl_mcts_leaf_states", "trl_mcts_root_children",
 ]
+
+GRID_FLOATS = 400
+VEC_FLOATS = 105
+POLICY_SIZE = 27 * 39 * 11
+
+
+class TrlMctsConfig(C.Structure):
+    """trl_mcts_config (include/tetris_engine.h); defaults = Config() of the reference, ai.py:63-138"""
+    _fields_ = [("max_iter", C.c_int32), ("training", C.c_int32), ("fpu_reduction", C.c_int32),
+                ("use_root_softmax", C.c_int32), ("use_playout_cap", C.c_int32), ("use_dirichlet", C.c_int32),
+                ("use_dir_s", C.c_int32), ("use_forced", C.c_int32), ("save_all", C.c_int32),
+                ("max_nodes", C.c_int32), ("record_capacity", C.c_int32), ("auto_reset", C.c_int32),
+                ("cpuct", C.c_double), ("dpuct", C.c_double), ("fpu_value", C.c_double),
+                ("root_softmax_temp", C.c_double), ("temperature", C.c_double),
+                ("playout_cap_chance", C.c_double), ("playout_cap_mult", C.c_double),
+                ("dir_alpha", C.c_double), ("dir_s", C.c_double), ("dir_expl", C.c_double), ("c_forced", C.c_double)]
+
+
+def mcts_config(**kw):
+    c = TrlMctsConfig(max_iter=400, training=0, fpu_reduction=1, use_root_softmax=1, use_playout_cap=1,
+                      use_dirichlet=1, use_dir_s=1, use_forced=0, save_all=0, max_nodes=0, record_capacity=0,
+                      auto_reset=1, cpuct=0.75, dpuct=1.0, fpu_value=0.1, root_softmax_temp=1.1, temperature=0.1,
+                      playout_cap_chance=0.25, playout_cap_mult=5.0, dir_alpha=0.1, dir_s=25.0, dir_expl=0.25,
+                      c_forced=1.0)
+    for k, v in kw.items():
+        if not hasattr(c, k):
+            raise TypeError("unknown search option %r" % k)
+        setattr(c, k, v)
+    return c
+
+
+RECORD_DTYPE = np.dtype([("slot", "<u4"), ("episode", "<u4"), ("ply", "<u4"), ("n_children", "<u2"), ("kind", "u1"),
+                         ("winner", "i1"), ("chosen", "<u2"), ("saved", "u1"), ("pad_", "u1"), ("pad2_", "<u4"),
+                         ("state", "u1", (320,)), ("moves", "<u2", (512,)), ("visits", "<u2", (512,))])
+assert RECORD_DTYPE.itemsize == 2392
+REC_MOVE, REC_GAME_END = 0, 1
+
+
+class TrlMctsStats(C.Structure):
+    _fields_ = [("ticks", C.c_uint64), ("simulations", C.c_uint64), ("moves", C.c_uint64), ("games", C.c_uint64),
+                ("records_dropped", C.c_uint64), ("max_nodes_used", C.c_uint32), ("overflow", C.c_uint32)]
+
 
 
 class TrlConfig(C.Structure):
@@ -42,6 +86,10 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     path = path or _build.LIB_PATH
+    # PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64; two HSA runtimes in one process cannot
+    # both open the device.  Loading torch first makes this library bind to the runtime torch uses
+    # (same soname), so engine buffers and torch tensors share one HIP context.
+    import torch  # noqa: F401
     if not os.path.isfile(path):
         raise EngineError("HIP engine library %s is missing: run `python __graft_entry__.py` (build()) first; "
                           "there is no CPU fallback" % path)
@@ -62,6 +110,13 @@ def load_library(path=None):
     L.trl_env_step_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.trl_env_rollout_random.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     L.trl_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.trl_mcts_create.argtypes = [C.c_void_p, C.POINTER(TrlMctsConfig)]
+    L.trl_mcts_select.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.trl_mcts_expand.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.trl_mcts_drain_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.trl_mcts_get_stats.argtypes = [C.c_void_p, C.POINTER(TrlMctsStats)]
+    L.trl_mcts_leaf_states.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.trl_mcts_root_children.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     _lib = L
     return L
 
@@ -159,6 +214,46 @@ class Engine:
 
     def set_stream(self, hip_stream):
         _check(self._L, self._L.trl_set_stream(self._h, hip_stream), "trl_set_stream")
+
+    # -- search ------------------------------------------------------------------------------
+    def mcts_create(self, cfg):
+        self._rec_cap = cfg.record_capacity if cfg.record_capacity > 0 else 16384
+        _check(self._L, self._L.trl_mcts_create(self._h, C.byref(cfg)), "trl_mcts_create")
+
+    def mcts_select(self, grids_ptr, vec_ptr):
+        _check(self._L, self._L.trl_mcts_select(self._h, grids_ptr, vec_ptr), "trl_mcts_select")
+
+    def mcts_expand(self, values_ptr, policy_ptr):
+        _check(self._L, self._L.trl_mcts_expand(self._h, values_ptr, policy_ptr), "trl_mcts_expand")
+
+    def mcts_drain_records(self):
+        buf = np.empty(self._rec_cap, dtype=RECORD_DTYPE)
+        n = C.c_int(0)
+        _check(self._L, self._L.trl_mcts_drain_records(self._h, buf.ctypes.data, self._rec_cap, C.byref(n)),
+               "trl_mcts_drain_records")
+        return buf[:n.value].copy()
+
+    def mcts_stats(self):
+        st = TrlMctsStats()
+        _check(self._L, self._L.trl_mcts_get_stats(self._h, C.byref(st)), "trl_mcts_get_stats")
+        return {k: getattr(st, k) for k, _ in st._fields_}
+
+    def mcts_leaf_states(self):
+        states = np.empty((self.n_games, STATE_BYTES), dtype=np.uint8)
+        info = np.empty((self.n_games, 4), dtype=np.int32)
+        _check(self._L, self._L.trl_mcts_leaf_states(self._h, states.ctypes.data, info.ctypes.data), "trl_mcts_leaf_states")
+        return states, info
+
+    def mcts_root_children(self):
+        n = self.n_games
+        counts = np.empty(n, dtype=np.int32)
+        moves = np.empty((n, MAX_LEGAL), dtype=np.uint16)
+        visits = np.empty((n, MAX_LEGAL), dtype=np.int32)
+        q = np.empty((n, MAX_LEGAL), dtype=np.float64)
+        p = np.empty((n, MAX_LEGAL), dtype=np.float64)
+        _check(self._L, self._L.trl_mcts_root_children(self._h, counts.ctypes.data, moves.ctypes.data, visits.ctypes.data,
+                                                       q.ctypes.data, p.ctypes.data), "trl_mcts_root_children")
+        return counts, moves, visits, q, p
 
 
 def encode_move(plane, col, row):
