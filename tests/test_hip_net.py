@@ -1,0 +1,105 @@
+"""GPU side of rows N1-N3 and D1-D3: features written by the search kernel == game_to_X, the net
+on the device within 1e-5 of the reference's logits, and the self-play driver (HIP graph tick)
+producing well-formed, deterministic training sets."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import tetris_rl_amd as trl
+from tetris_rl_amd import records
+from test_net_parity import load_net, packed_features, TOL
+
+pytestmark = pytest.mark.gpu
+
+
+def test_kernel_features_match_game_to_x(golden_dir):
+    d = np.load(os.path.join(golden_dir, "env_traces.npz"))
+    idx = np.arange(0, d["states"].shape[0], 37)[:128]
+    states = d["states"][idx]
+    eng = trl.Engine(len(idx), seed=1)
+    eng.set_state(states)
+    eng.mcts_create(trl.mcts_config(max_iter=4, training=0, auto_reset=0))
+    dev = torch.device("cuda", 0)
+    grids = torch.zeros((2, len(idx), 400), dtype=torch.float32, device=dev)
+    vec = torch.zeros((len(idx), 105), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    eng.mcts_select(grids.data_ptr(), vec.data_ptr())          # first tick: the leaf is the root itself
+    leaf, info = eng.mcts_leaf_states()
+    g, v = grids.cpu().numpy(), vec.cpu().numpy()
+    want_g, want_v = packed_features(leaf)
+    assert np.array_equal(g, want_g) and np.array_equal(v, want_v)
+    # the root copy restricts previews to 5 (ai.py:306-309); everything else equals the input position
+    for i in range(len(idx)):
+        a, b = leaf[i].copy(), states[i].copy()
+        for pl in (0, 144):
+            ql = min(int(b[pl + 139]), 5)
+            b[pl + 139] = ql
+            q = int.from_bytes(bytes(b[pl + 112:pl + 120]), "little") & ((1 << (4 * ql)) - 1)
+            b[pl + 112:pl + 120] = np.frombuffer(q.to_bytes(8, "little"), dtype=np.uint8)
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("tag,blocks,filters", [("b10f16", 10, 16), ("b2f8", 2, 8)])
+def test_net_on_device_matches_reference(golden_dir, tag, blocks, filters):
+    d = np.load(os.path.join(golden_dir, "net.npz"))
+    net = load_net(d, tag, blocks, filters, device="cuda")
+    grids, vec = packed_features(d["states"])
+    v, logits = net.heads(torch.from_numpy(grids).cuda(), torch.from_numpy(vec).cuda())
+    assert np.abs(torch.sigmoid(v).cpu().numpy() - d["%s/values" % tag]).max() < TOL
+    assert np.abs(logits.cpu().numpy() - d["%s/logits" % tag]).max() < TOL
+    # batch invariance: the same positions inside a batch of 512 give the same numbers to 1e-5
+    reps = 64
+    vb, lb = net.heads(torch.from_numpy(np.tile(grids, (1, reps, 1))).cuda(), torch.from_numpy(np.tile(vec, (reps, 1))).cuda())
+    assert np.abs(lb[:8].cpu().numpy() - d["%s/logits" % tag]).max() < TOL
+
+
+def _tiny_cfg(**kw):
+    return trl.Config(visual=False, model="pytorch", model_config=trl.AlphaSameConfig(blocks=2, filters=8), MAX_ITER=8,
+                      training=True, **kw)
+
+
+def test_make_training_set_is_wellformed_and_deterministic(tmp_path, monkeypatch):
+    monkeypatch.setenv("TRL_STORAGE", str(tmp_path / "Storage"))
+    torch.manual_seed(0)
+    net = trl.AlphaSame(trl.AlphaSameConfig(blocks=2, filters=8))
+    cfg = _tiny_cfg()
+    a = trl.make_training_set(cfg, net, 6, save_stats=False, seed=11)
+    b = trl.make_training_set(cfg, net, 6, save_stats=False, seed=11)
+    assert len(a) > 0 and len(a) % 4 == 0            # x4 mirror augmentation
+    import json
+    assert json.dumps(a) == json.dumps(b)
+    rec = a[0]
+    assert len(rec) == 13 and len(rec[0]) == 40 and len(rec[0][0]) == 10 and len(rec[1]) == 7
+    assert rec[11] in (0, 1, 0.5) and len(rec[12]) == 27 and len(rec[12][0]) == 39 and len(rec[12][0][0]) == 11
+    s = sum(sum(sum(r) for r in plane) for plane in rec[12])
+    assert abs(s - 1.0) < 0.02
+    # files: {data_dir}/{n}.txt and logs/stats.jsonl as the reference writes them
+    trl.make_training_set(cfg, net, 2, save_game=True, save_stats=True, seed=3)
+    assert os.path.isfile(os.path.join(cfg.data_dir, "0.txt"))
+    assert os.path.isfile(tmp_path / "Storage" / "logs" / "stats.jsonl")
+    data = json.load(open(os.path.join(cfg.data_dir, "0.txt")))
+    assert isinstance(data, list) and len(data[0]) == 13
+
+
+def test_graph_and_eager_ticks_agree():
+    torch.manual_seed(0)
+    net = trl.AlphaSame(trl.AlphaSameConfig(blocks=2, filters=8))
+    out = []
+    for use_graph in (True, False):
+        sp = trl.SelfPlay(_tiny_cfg(), net, 16, seed=5, use_graph=use_graph, auto_reset=False)
+        sp.tick(200)
+        r = sp.drain()
+        r = r[np.lexsort((r["ply"], r["slot"]))]
+        out.append(r)
+    assert len(out[0]) == len(out[1]) and len(out[0]) > 0
+    assert np.array_equal(out[0]["chosen"], out[1]["chosen"]) and np.array_equal(out[0]["visits"], out[1]["visits"])
+
+
+def test_self_play_loop_writes_sets(tmp_path, monkeypatch):
+    monkeypatch.setenv("TRL_STORAGE", str(tmp_path / "Storage"))
+    cfg = _tiny_cfg(training_games=3)
+    cfg.training = False
+    n = trl.self_play_loop(cfg, max_sets=2, seed=1)
+    assert n == 2 and trl.highest_data_number(cfg) == 1 and trl.highest_model_number(cfg) == 0

@@ -1,0 +1,79 @@
+"""AlphaSame inference module against the reference's module (fixture oracle/gen_golden_net.py):
+same state_dict keys, value and all 11 583 policy logits within 1e-5 (fp32), for two
+architectures.  CPU here; tests/test_hip_net.py repeats it on the GPU with the packed features
+the search kernel writes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import net_fixture
+from tetris_rl_amd import nets, records
+
+TOL = 1e-5
+
+
+def load_net(d, tag, blocks, filters, device="cpu"):
+    net = nets.AlphaSame(nets.AlphaSameConfig(blocks=blocks, filters=filters))
+    keys = [str(k) for k in d["%s/keys" % tag]]
+    assert list(net.state_dict().keys()) == keys, "state_dict keys differ from the reference's"
+    sd = {}
+    w, b = net_fixture.policy_head()
+    for k in keys:
+        if k == "policy_head.weight":
+            sd[k] = torch.from_numpy(w)
+        elif k == "policy_head.bias":
+            sd[k] = torch.from_numpy(b)
+        else:
+            sd[k] = torch.from_numpy(d["%s/%s" % (tag, k)])
+    net.load_state_dict(sd)
+    return net.to(device).prepare()
+
+
+def packed_features(states):
+    """grids [2, n, 400], vec [n, 105] from canonical states via the host-side game_to_X"""
+    n = len(states)
+    grids = np.zeros((2, n, 400), dtype=np.float32)
+    vec = np.zeros((n, 105), dtype=np.float32)
+    for i, st in enumerate(states):
+        x = records.game_to_x(st)
+        grids[0, i], grids[1, i] = x[0].reshape(-1), x[5].reshape(-1)
+        vec[i] = np.concatenate([x[1].reshape(-1), [x[2], x[3], x[4]], x[6].reshape(-1), [x[7], x[8], x[9]], [x[10]]])
+    return grids, vec
+
+
+@pytest.mark.parametrize("tag,blocks,filters", [("b10f16", 10, 16), ("b2f8", 2, 8)])
+def test_logits_and_value_match_reference(golden_dir, tag, blocks, filters):
+    d = np.load(os.path.join(golden_dir, "net.npz"))
+    net = load_net(d, tag, blocks, filters)
+    grids, vec = packed_features(d["states"])
+    # host-side features == the reference's game_to_X output
+    ref = d["ref_features"]
+    mine = np.concatenate([grids[0], vec[:, :52], grids[1], vec[:, 52:]], axis=1)
+    assert np.array_equal(mine, ref)
+    v, logits = net.heads(torch.from_numpy(grids), torch.from_numpy(vec))
+    v = torch.sigmoid(v).numpy()
+    assert np.abs(v - d["%s/values" % tag]).max() < TOL
+    assert np.abs(logits.numpy() - d["%s/logits" % tag]).max() < TOL
+    # the reference's 11-tensor signature gives the same numbers
+    n = len(d["states"])
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    out_v, out_p = net(t(grids[0]).reshape(n, 1, 40, 10), t(vec[:, :49]).reshape(n, 7, 7), t(vec[:, 49]), t(vec[:, 50]),
+                       t(vec[:, 51]), t(grids[1]).reshape(n, 1, 40, 10), t(vec[:, 52:101]).reshape(n, 7, 7), t(vec[:, 101]),
+                       t(vec[:, 102]), t(vec[:, 103]), t(vec[:, 104]))
+    assert np.abs(out_p.numpy() - d["%s/logits" % tag]).max() < TOL
+    assert np.abs(out_v.numpy().reshape(-1) - d["%s/values" % tag]).max() < TOL
+
+
+def test_reference_checkpoint_roundtrip(tmp_path, golden_dir):
+    d = np.load(os.path.join(golden_dir, "net.npz"))
+    net = load_net(d, "b2f8", 2, 8)
+    path = os.path.join(tmp_path, "3.pt")
+    torch.save(net.state_dict(), path)
+    net2 = nets.load_reference_checkpoint(path, nets.AlphaSameConfig(blocks=2, filters=8))
+    grids, vec = packed_features(d["states"])
+    a = net.evaluate_packed(torch.from_numpy(grids), torch.from_numpy(vec))
+    b = net2.evaluate_packed(torch.from_numpy(grids), torch.from_numpy(vec))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert abs(float(a[1].sum(dim=1)[0]) - 1.0) < 1e-5

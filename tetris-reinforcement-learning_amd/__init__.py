@@ -10,3 +10,6 @@ from . import build as _build_mod
 
 def build(force=False, verbose=False):
     return _build_mod.build(force=force, verbose=verbose)
+from .selfplay import (Config, SelfPlay, GameCollector, play_game, make_training_set, self_play_loop,  # noqa: F401,E402
+                       instantiate_network, load_best_model, highest_model_number, highest_data_number, search_options)
+from .nets import AlphaSame, AlphaSameConfig  # noqa: F401,E402

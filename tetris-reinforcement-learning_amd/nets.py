@@ -1,0 +1,162 @@
+"""Policy/value net of the rollout path.
+
+`AlphaSame` carries the reference's parameter names (architectures.py:60-142, state_dict keys in
+SURVEY Appendix C) so `{n}.pt` files written by the reference load unchanged, but it is an
+inference module with its own forward:
+
+  * input is the packed feature layout the search kernel writes (trl_mcts_select): `grids`
+    float[2][n][40*10] (side to move first, then opponent) and `vec` float[n][105];
+  * both boards of all n leaves go through the residual tower as ONE batch of 2n images;
+  * eval-mode batch norms are folded at `prepare()` time: the norm that follows a convolution
+    directly (conv_block2's) into that convolution's weights, the others into per-channel
+    scale/shift pairs applied with the ReLU; dense + BatchNorm1d pairs into one affine map;
+  * output is what evaluate() returns (ai.py:1222-1319): sigmoid value [n] and softmaxed policy
+    [n, 11583].
+"""
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+ROWS, COLS = 40, 10
+POLICY_SIZE = 27 * 39 * 11
+PIECES_PER_PLAYER = 7 * 7
+SCALARS_PER_PLAYER = 3
+
+
+class AlphaSameConfig:
+    """architectures.py:8-17 (only the fields the PyTorch net reads)"""
+
+    def __init__(self, blocks=10, pooling_blocks=2, filters=16, cpool=4, dropout=0.25, kernels=1,
+                 o_side_neurons=16, value_head_neurons=16):
+        self.blocks, self.pooling_blocks, self.filters, self.cpool = blocks, pooling_blocks, filters, cpool
+        self.dropout, self.kernels = dropout, kernels
+        self.o_side_neurons, self.value_head_neurons = o_side_neurons, value_head_neurons
+
+
+def _bn2d(c):
+    return nn.BatchNorm2d(c)
+
+
+class _Block(nn.Module):
+    """parameter holder for one residual block: conv_block1 = {0: BN, 2: conv}, conv_block2 = {0: BN, 3: conv}"""
+
+    def __init__(self, f):
+        super().__init__()
+        self.conv_block1 = nn.ModuleDict({"0": _bn2d(f), "2": nn.Conv2d(f, f, 3, padding=1, bias=False)})
+        self.conv_block2 = nn.ModuleDict({"0": _bn2d(f), "3": nn.Conv2d(f, f, 3, padding=1, bias=False)})
+
+
+def _affine(bn):
+    s = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    return s, bn.bias - bn.running_mean * s
+
+
+class AlphaSame(nn.Module):
+    def __init__(self, model_config=None, use_tanh=False):
+        super().__init__()
+        mc = model_config or AlphaSameConfig()
+        if mc.kernels != 1:
+            raise ValueError("only kernels=1 is supported (the reference default)")
+        self.model_config, self.use_tanh = mc, use_tanh
+        f = mc.filters
+        self.conv1 = nn.Conv2d(1, f, 5, padding=2, bias=False)
+        self.res_blocks = nn.ModuleList([_Block(f) for _ in range(mc.blocks)])
+        self.batchnorm1 = _bn2d(f)
+        self.kernel1 = nn.Conv2d(f, mc.kernels, 1, bias=False)
+        self.batchnorm2 = _bn2d(mc.kernels)
+        grid_out = ROWS * COLS * mc.kernels
+        self.osidedense = nn.ModuleDict({"0": nn.Linear(grid_out, mc.o_side_neurons), "1": nn.BatchNorm1d(mc.o_side_neurons)})
+        head_in = grid_out + mc.o_side_neurons + 2 * PIECES_PER_PLAYER + 2 * SCALARS_PER_PLAYER + 1      # 521
+        self.policy_head = nn.Linear(head_in, POLICY_SIZE)
+        self.value_head = nn.ModuleDict({"0": nn.Linear(head_in, mc.value_head_neurons),
+                                         "1": nn.BatchNorm1d(mc.value_head_neurons),
+                                         "3": nn.Linear(mc.value_head_neurons, 1)})
+        self._folded = None
+        self.eval()
+
+    # -- folding ------------------------------------------------------------------------------
+    @torch.no_grad()
+    def prepare(self):
+        """fold the eval-mode batch norms; call after loading weights / moving devices"""
+        fd = {"blocks": []}
+        for blk in self.res_blocks:
+            s1, t1 = _affine(blk.conv_block1["0"])
+            s2, t2 = _affine(blk.conv_block2["0"])
+            wa = blk.conv_block1["2"].weight * s2.view(-1, 1, 1, 1)
+            fd["blocks"].append((s1.view(1, -1, 1, 1).contiguous(), t1.view(1, -1, 1, 1).contiguous(),
+                                 wa.contiguous(), t2.contiguous(), blk.conv_block2["3"].weight.contiguous()))
+        s, t = _affine(self.batchnorm1)
+        fd["tail"] = (s.view(1, -1, 1, 1).contiguous(), t.view(1, -1, 1, 1).contiguous())
+        sk, tk = _affine(self.batchnorm2)
+        fd["k1"] = ((self.kernel1.weight * sk.view(-1, 1, 1, 1)).contiguous(), tk.contiguous())
+        so, to = _affine(self.osidedense["1"])
+        fd["oside"] = ((self.osidedense["0"].weight * so.view(-1, 1)).contiguous(), (self.osidedense["0"].bias * so + to).contiguous())
+        sv, tv = _affine(self.value_head["1"])
+        fd["v0"] = ((self.value_head["0"].weight * sv.view(-1, 1)).contiguous(), (self.value_head["0"].bias * sv + tv).contiguous())
+        self._folded = fd
+        return self
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._folded = None
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._folded = None
+        return r
+
+    # -- inference ----------------------------------------------------------------------------
+    @torch.no_grad()
+    def trunk(self, boards):
+        """boards float[m, 1, 40, 10] -> float[m, 400] (process_grid of the reference, architectures.py:121-127)"""
+        fd = self._folded or self.prepare()._folded
+        x = F.conv2d(boards, self.conv1.weight, padding=2)
+        for s1, t1, wa, ba, wb in fd["blocks"]:
+            h = torch.relu(x * s1 + t1)
+            h = torch.relu(F.conv2d(h, wa, ba, padding=1))
+            x = x + F.conv2d(h, wb, padding=1)
+        s, t = fd["tail"]
+        wk, bk = fd["k1"]
+        return torch.relu(F.conv2d(torch.relu(x * s + t), wk, bk)).flatten(1)
+
+    @torch.no_grad()
+    def heads(self, grids, vec):
+        """-> (value_pre_activation [n], policy logits [n, 11583])"""
+        fd = self._folded or self.prepare()._folded
+        n = vec.shape[0]
+        z = self.trunk(grids.reshape(2 * n, 1, ROWS, COLS))
+        wo, bo = fd["oside"]
+        o = torch.relu(F.linear(z[n:], wo, bo))
+        # concat order of the reference (architectures.py:132-140)
+        x = torch.cat([z[:n], vec[:, :52], o, vec[:, 52:]], dim=1)
+        wv, bv = fd["v0"]
+        v = F.linear(torch.relu(F.linear(x, wv, bv)), self.value_head["3"].weight, self.value_head["3"].bias)
+        return v.reshape(n), F.linear(x, self.policy_head.weight, self.policy_head.bias)
+
+    @torch.no_grad()
+    def evaluate_packed(self, grids, vec):
+        """(value [n], softmaxed policy [n, 11583]) -- evaluate() of the reference on a batch"""
+        v, logits = self.heads(grids, vec)
+        v = torch.tanh(v) if self.use_tanh else torch.sigmoid(v)
+        return v, torch.softmax(logits, dim=1)
+
+    def forward(self, a_grid, a_pieces, a_b2b, a_combo, a_garbage, o_grid, o_pieces, o_b2b, o_combo, o_garbage, color):
+        """the reference's 11-tensor signature (architectures.py:119-142), batch-first"""
+        n = a_grid.shape[0]
+        grids = torch.stack([a_grid.reshape(n, -1), o_grid.reshape(n, -1)]).to(torch.float32)
+        cols = [a_pieces.reshape(n, -1), a_b2b.reshape(n, 1), a_combo.reshape(n, 1), a_garbage.reshape(n, 1),
+                o_pieces.reshape(n, -1), o_b2b.reshape(n, 1), o_combo.reshape(n, 1), o_garbage.reshape(n, 1),
+                color.reshape(n, 1)]
+        vec = torch.cat([c.to(torch.float32) for c in cols], dim=1)
+        v, logits = self.heads(grids, vec)
+        v = torch.tanh(v) if self.use_tanh else torch.sigmoid(v)
+        return v.reshape(n, 1), logits
+
+
+def load_reference_checkpoint(path, model_config=None, device="cpu"):
+    """`torch.save(model.state_dict(), '{n}.pt')` files of the reference (ai.py:1082, 2192)"""
+    net = AlphaSame(model_config)
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    net.load_state_dict(sd)
+    return net.to(device).prepare()

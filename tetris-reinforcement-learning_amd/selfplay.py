@@ -1,0 +1,315 @@
+"""Self-play data generation behind the reference's Config / play_game / make_training_set /
+self_play_loop interface (ai.py:62-216, 1570-1699, 1809-1869, 2117-2198; seams S1-S4, S9 of
+SURVEY.md section 8b).
+
+All games of a set run concurrently as slots of one Engine; every tick is
+    trl_mcts_select -> AlphaSame.evaluate_packed (PyTorch-ROCm) -> trl_mcts_expand
+on one HIP stream, captured once into a HIP graph and replayed.  Records come back from the
+device as (position, root children (move, N)) and are turned into the reference's 13-field
+lists on the host (records.py).
+"""
+import json
+import math
+import os
+from pathlib import Path
+
+import numpy as np
+
+from . import engine as _eng
+from . import nets, records
+
+
+# ---- S1: Config ---------------------------------------------------------------------------------------
+_CONFIG_DEFAULTS = dict(           # ai.py:63-138, same names, same defaults
+    visual=True, model_version=7.0, data_version=2.9, ruleset="s2", model="keras", use_tflite=True,
+    tflite_num_threads=2, batched_inference=False, model_config=None, move_algorithm="convolutional",
+    use_tanh=False, training_games=100, training_loops=1, sets_to_train_with=10, battle_games=200,
+    gating_threshold=0.52, gating_threshold_type="moreorequal", MAX_ITER=400, CPUCT=0.75, DPUCT=1,
+    FpuStrategy="reduction", FpuValue=0.1, use_root_softmax=True, RootSoftmaxTemp=1.1, temperature=0.1,
+    training=False, learning_rate=0.001, weight_decay=0.0, epochs=1, batch_size=64, data_loading_style="merge",
+    decay_factor=0.9, augment_data=True, shuffle=True, use_experimental_features=False, save_all=False,
+    loss_weights=[1, 1], use_random_starting_moves=False, use_playout_cap_randomization=True,
+    playout_cap_chance=0.25, playout_cap_mult=5, use_dirichlet_noise=True, DIRICHLET_ALPHA=0.1, DIRICHLET_S=25,
+    DIRICHLET_EXPLORATION=0.25, use_dirichlet_s=True, use_forced_playouts_and_policy_target_pruning=False,
+    CForcedPlayout=1,
+)
+
+
+def storage_root():
+    """ai.py:57-59: Path.cwd().parent / 'Storage' (overridable with TRL_STORAGE)"""
+    return Path(os.environ.get("TRL_STORAGE", Path.cwd().parent / "Storage"))
+
+
+class Config:
+    """Same keyword arguments and derived properties as the reference's Config; an unknown
+    keyword raises TypeError as a Python signature would."""
+
+    def __init__(self, **kwargs):
+        for k in kwargs:
+            if k not in _CONFIG_DEFAULTS:
+                raise TypeError("Config.__init__() got an unexpected keyword argument %r" % k)
+        for k, v in _CONFIG_DEFAULTS.items():
+            setattr(self, k, kwargs.get(k, list(v) if isinstance(v, list) else v))
+        if self.model_config is None:
+            self.model_config = nets.AlphaSameConfig()
+
+    def copy(self):
+        return Config(**{k: getattr(self, k) for k in _CONFIG_DEFAULTS})
+
+    @property
+    def model_dir(self):
+        sub = "pytorch_models" if self.model == "pytorch" else "models"
+        return "%s/%s/%s.%s" % (storage_root(), sub, self.ruleset, self.model_version)
+
+    @property
+    def data_dir(self):
+        return "%s/data/%s.%s" % (storage_root(), self.ruleset, self.data_version)
+
+    @property
+    def value_max(self):
+        return 1
+
+    @property
+    def value_mid(self):
+        return 0 if self.use_tanh else 0.5
+
+    @property
+    def value_min(self):
+        return -1 if self.use_tanh else 0
+
+    def negate_value(self, value):
+        return -value if self.use_tanh else 1 - value
+
+
+def search_options(config, **extra):
+    """Config -> trl_mcts_config"""
+    if config.move_algorithm != "convolutional":
+        raise ValueError("Unknown algorithm: %s (the device implements the reference default 'convolutional')"
+                         % config.move_algorithm)
+    if config.use_tanh:
+        raise ValueError("use_tanh=True is not supported by the device search (value range [0, 1] only)")
+    if config.FpuStrategy not in ("reduction", "absolute"):
+        raise ValueError("Unknown FpuStrategy: %s" % config.FpuStrategy)
+    if config.use_random_starting_moves:
+        raise ValueError("use_random_starting_moves is not supported by the device driver")
+    opts = dict(max_iter=int(config.MAX_ITER), training=int(bool(config.training)),
+                fpu_reduction=int(config.FpuStrategy == "reduction"), use_root_softmax=int(bool(config.use_root_softmax)),
+                use_playout_cap=int(bool(config.use_playout_cap_randomization)),
+                use_dirichlet=int(bool(config.use_dirichlet_noise)), use_dir_s=int(bool(config.use_dirichlet_s)),
+                use_forced=int(bool(config.use_forced_playouts_and_policy_target_pruning)),
+                save_all=int(bool(config.save_all)), cpuct=float(config.CPUCT), dpuct=float(config.DPUCT),
+                fpu_value=float(config.FpuValue), root_softmax_temp=float(config.RootSoftmaxTemp),
+                temperature=float(config.temperature), playout_cap_chance=float(config.playout_cap_chance),
+                playout_cap_mult=float(config.playout_cap_mult), dir_alpha=float(config.DIRICHLET_ALPHA),
+                dir_s=float(config.DIRICHLET_S), dir_expl=float(config.DIRICHLET_EXPLORATION),
+                c_forced=float(config.CForcedPlayout))
+    opts.update(extra)
+    return _eng.mcts_config(**opts)
+
+
+# ---- the tick loop ----------------------------------------------------------------------------------------
+class SelfPlay:
+    """n_slots concurrent self-play games: Engine + net + HIP-graph tick."""
+
+    def __init__(self, config, network, n_slots, seed=0, device=0, streams=None, auto_reset=True, use_graph=True,
+                 max_nodes=0, record_capacity=0):
+        import torch
+        self.torch = torch
+        self.config = config
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.net = network.to(self.device).prepare()
+        self.n = int(n_slots)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.engine = _eng.Engine(self.n, ruleset=config.ruleset, seed=seed, device=device, stream=self.stream.cuda_stream)
+        self.engine.reset(streams)
+        self.engine.mcts_create(search_options(config, auto_reset=int(bool(auto_reset)), max_nodes=max_nodes,
+                                               record_capacity=record_capacity))
+        with torch.cuda.stream(self.stream):
+            self.grids = torch.zeros((2, self.n, _eng.GRID_FLOATS), dtype=torch.float32, device=self.device)
+            self.vec = torch.zeros((self.n, _eng.VEC_FLOATS), dtype=torch.float32, device=self.device)
+        self.stream.synchronize()
+        self.graph = None
+        self.ticks = 0
+        if use_graph:
+            self._capture()
+
+    def _tick_body(self):
+        e = self.engine
+        e.mcts_select(self.grids.data_ptr(), self.vec.data_ptr())
+        v, p = self.net.evaluate_packed(self.grids, self.vec)
+        # v / p live in the stream-ordered allocator (a fixed address inside a captured graph)
+        e.mcts_expand(v.data_ptr(), p.data_ptr())
+
+    def _capture(self):
+        torch = self.torch
+        with torch.cuda.stream(self.stream):
+            # one eager evaluation outside the capture warms up MIOpen / rocBLAS handles and workspaces
+            self.net.evaluate_packed(self.grids, self.vec)
+        self.stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=self.stream):
+            self._tick_body()
+        self.graph = g
+
+    def tick(self, n=1):
+        torch = self.torch
+        with torch.cuda.stream(self.stream):           # graph replays launch on the current stream
+            for _ in range(n):
+                if self.graph is not None:
+                    self.graph.replay()
+                else:
+                    self._tick_body()
+        self.ticks += n
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    def drain(self):
+        self.stream.synchronize()
+        return self.engine.mcts_drain_records()
+
+    def stats(self):
+        self.stream.synchronize()
+        return self.engine.mcts_stats()
+
+
+class GameCollector:
+    """Groups the device's record stream into finished games and builds the reference's per-game
+    `data` lists (ai.py:1613-1695)."""
+
+    def __init__(self, config):
+        self.config = config
+        self.open = {}            # (slot, episode) -> list of move records
+        self.finished = []        # dicts: key, data, stats, plies, winner
+
+    def add(self, recs):
+        for r in recs:
+            key = (int(r["slot"]), int(r["episode"]))
+            if r["kind"] == _eng.REC_MOVE:
+                self.open.setdefault(key, []).append(r.copy())
+            else:
+                moves = sorted(self.open.pop(key, []), key=lambda x: int(x["ply"]))
+                game_data = [[], []]
+                for m in moves:
+                    if m["saved"]:
+                        n = int(m["n_children"])
+                        game_data[int(m["state"][312])] += records.records_for_move(
+                            m["state"], m["moves"][:n], m["visits"][:n], augment=self.config.augment_data)
+                c = self.config
+                data = records.finish_game(game_data, int(r["winner"]), c.value_min, c.value_mid, c.value_max)
+                p0 = records.unpack_player(r["state"][0:144])
+                stats = {"app": p0["lines_sent"] / max(p0["pieces"], 1), "dspp": p0["lines_cleared"] / max(p0["pieces"], 1)}
+                self.finished.append(dict(key=key, data=data, stats=stats, plies=int(r["ply"]), winner=int(r["winner"]),
+                                          moves=[int(m["chosen"]) for m in moves]))
+
+
+# ---- model / data numbering (ai.py:2306-2355) ------------------------------------------------------------------
+def _highest_number(path, strip=None):
+    os.makedirs(path, exist_ok=True)
+    best = -1
+    for name in os.listdir(path):
+        stem = name[:-len(strip)] if (strip and name.endswith(strip)) else name.split(".")[0]
+        if stem.isdigit():
+            best = max(best, int(stem))
+    return best
+
+
+def highest_model_number(config):
+    return _highest_number(config.model_dir, ".pt" if config.model == "pytorch" else None)
+
+
+def highest_data_number(config):
+    return _highest_number(config.data_dir)
+
+
+def instantiate_network(config, nn_generator=None, show_summary=False, save_network=True):
+    """ai.py:1033-1085 for the PyTorch AlphaSame family: random-init net, saved as {n}.pt"""
+    import torch
+    net = (nn_generator or nets.AlphaSame)(config.model_config)
+    if save_network:
+        os.makedirs(config.model_dir, exist_ok=True)
+        torch.save(net.state_dict(), "%s/%d.pt" % (config.model_dir, highest_model_number(config) + 1))
+    return net
+
+
+def load_best_model(config):
+    n = highest_model_number(config)
+    if n < 0:
+        return instantiate_network(config)
+    return nets.load_reference_checkpoint("%s/%d.pt" % (config.model_dir, n), config.model_config)
+
+
+# ---- S3 / S4: make_training_set, play_game --------------------------------------------------------------------------
+def _run_games(config, network, num_games, seed, device=0, max_slots=1024, streams=None):
+    slots = min(int(num_games), int(max_slots))
+    sp = SelfPlay(config, network, slots, seed=seed, device=device, streams=streams, auto_reset=num_games > slots)
+    col = GameCollector(config)
+    chunk = 64
+    while len(col.finished) < num_games:
+        sp.tick(chunk)
+        col.add(sp.drain())
+        st = sp.stats()
+        if st["records_dropped"] or st["overflow"]:
+            raise _eng.EngineError("device record buffer or tree capacity overflowed: %r" % (st,))
+    col.finished.sort(key=lambda g: (g["key"][1], g["key"][0]))
+    return col.finished[:num_games], sp
+
+
+def play_game(config, interference_network, game_number=None, screen=None, seed=0):
+    """One self-play game -> (data, stats) as ai.py:1570-1699 (screen is ignored: no UI)."""
+    games, _ = _run_games(config, interference_network, 1, seed,
+                          streams=None if game_number is None else np.array([game_number], dtype=np.uint32))
+    g = games[0]
+    stats = {"model_number": highest_model_number(config), "model_version": config.model_version,
+             "data_number": highest_data_number(config) + 1, "data_version": config.data_version,
+             "app": g["stats"]["app"], "dspp": g["stats"]["dspp"]}
+    return g["data"], stats
+
+
+def make_training_set(config, interference_network, num_games, save_game=False, save_stats=True, screen=None, seed=0,
+                      max_slots=1024):
+    """ai.py:1809-1845: plays num_games games, optionally writes {data_dir}/{n}.txt and the averaged
+    stats line; returns the records only when save_stats is False (as the reference does)."""
+    games, _ = _run_games(config, interference_network, num_games, seed, max_slots=max_slots)
+    series_data, series_stats = [], []
+    for g in games:
+        series_data.extend(g["data"])
+        series_stats.append(g["stats"])
+    if save_game:
+        next_set = highest_data_number(config) + 1
+        with open("%s/%d.txt" % (config.data_dir, next_set), "w") as f:
+            f.write(json.dumps(series_data))
+    if save_stats:
+        logs = storage_root() / "logs"
+        logs.mkdir(parents=True, exist_ok=True)
+        line = {"model_number": highest_model_number(config), "model_version": config.model_version,
+                "data_number": highest_data_number(config) + (0 if save_game else 1), "data_version": config.data_version,
+                "app": round(sum(s["app"] for s in series_stats) / len(series_stats), 3),
+                "dspp": round(sum(s["dspp"] for s in series_stats) / len(series_stats), 3)}
+        with open(logs / "stats.jsonl", "a") as f:
+            f.write(json.dumps(line) + "\n")
+        return None
+    return series_data
+
+
+def self_play_loop(config, skip_first_set=False, max_sets=None, train_fn=None, gate_fn=None, seed=0):
+    """ai.py:2117-2198, data-generation side: repeatedly plays `training_games` games with the best
+    model on disk and writes one data set per loop.  The learner and the gating match are outside
+    the rollout path; `train_fn(config)` / `gate_fn(config)` are called where the
+    reference runs them, if given.  `max_sets` bounds the otherwise endless loop."""
+    if highest_model_number(config) == -1:
+        instantiate_network(config, save_network=True)
+    sets = 0
+    while max_sets is None or sets < max_sets:
+        net = load_best_model(config)
+        tc = config.copy()
+        tc.training = True
+        if not (skip_first_set and sets == 0):
+            make_training_set(tc, net, config.training_games, save_game=True, save_stats=True, seed=seed + sets)
+        if train_fn is not None:
+            train_fn(config)
+        if gate_fn is not None:
+            gate_fn(config)
+        sets += 1
+    return sets
