@@ -272,6 +272,16 @@ int  trl_mcts_leaf_states(trl_engine *h, trl_game_state *host_out, int32_t *host
 /* root children of every slot's current tree: counts[n], moves / visits [n][TRL_MAX_LEGAL], q / p as fp64 */
 int  trl_mcts_root_children(trl_engine *h, int32_t *counts, uint16_t *moves, int32_t *visits, double *q, double *p);
 
+/* ==== net: residual tower of AlphaSame on the device (architectures.py:27-57, 119-127) ===========
+ * process_grid for filters = 16, kernels = 1: conv5x5 -> n_blocks residual blocks -> BN, ReLU ->
+ * conv1x1 -> BN, ReLU -> flatten, one workgroup per board, fp32 MFMA, activations resident in LDS.
+ * dev_boards float[n_boards][400], dev_out float[n_boards][400]; dev_packed = the weights with the
+ * eval-mode batch norms folded, in the layout documented in csrc/trl_net.hip (built by
+ * nets.AlphaSame.prepare()): conv1 [16][25]; per block s1[16] t1[16] Wa[9][4][64] ba[16] Wb[9][4][64];
+ * tail s[16] t[16] wk[16] bk.  stream: hipStream_t (NULL = default stream).                        */
+int  trl_alphasame_trunk16(const float *dev_boards, int n_boards, const float *dev_packed, int n_blocks,
+                           float *dev_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,3 +103,26 @@ def test_self_play_loop_writes_sets(tmp_path, monkeypatch):
     cfg.training = False
     n = trl.self_play_loop(cfg, max_sets=2, seed=1)
     assert n == 2 and trl.highest_data_number(cfg) == 1 and trl.highest_model_number(cfg) == 0
+
+
+def test_fused_hip_tower_matches_torch_tower(golden_dir):
+    """csrc/trl_net.hip (fp32 MFMA, activations in LDS) against the same tower as PyTorch ops, on
+    random occupancy boards incl. full, empty and checkerboard ones; fp32 tolerance 2e-5 absolute on
+    outputs of magnitude ~1 (different summation order only)."""
+    d = np.load(os.path.join(golden_dir, "net.npz"))
+    net = load_net(d, "b10f16", 10, 16, device="cuda")
+    assert net._folded["packed16"] is not None
+    g = torch.Generator().manual_seed(3)
+    m = 515
+    boards = (torch.rand((m, 1, 40, 10), generator=g) < torch.rand((m, 1, 1, 1), generator=g)).float()
+    boards[0] = 0; boards[1] = 1
+    boards[2, 0] = torch.from_numpy((np.indices((40, 10)).sum(0) % 2).astype(np.float32))
+    boards = boards.cuda()
+    net.use_hip_trunk = True
+    a = net.trunk(boards)
+    net.use_hip_trunk = False
+    b = net.trunk(boards)
+    net.use_hip_trunk = True
+    assert a.shape == b.shape == (m, 400)
+    assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
+    assert float(b.abs().max()) > 0.01

@@ -9,7 +9,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libtrl_hip.so")
-SOURCES = ["trl_engine.hip", "trl_mcts.hip"]
+SOURCES = ["trl_engine.hip", "trl_mcts.hip", "trl_net.hip"]
 HEADERS = ["trl_device.h", "trl_tables.h", "trl_internal.h", os.path.join("..", "..", "include", "tetris_engine.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
                # the search mirrors the reference's per-operation rounding: no fused multiply-add, IEEE divide/sqrt

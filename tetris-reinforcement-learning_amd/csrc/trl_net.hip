@@ -1,0 +1,184 @@
+// trl_net.hip -- fused residual tower of AlphaSame for 16 filters (architectures.py:27-57, 119-127):
+//   conv5x5(1->16) -> B x [BN, ReLU, conv3x3, BN, ReLU, conv3x3, +x] -> BN, ReLU -> conv1x1(16->1) -> BN, ReLU
+// one 256-thread workgroup per 40x10 board, every activation of the board resident on the CU.
+//
+// Mapping (gfx950):
+//   * a 3x3 convolution over 16 channels is the GEMM  out[400 x 16] = im2col[400 x 144] . W[144 x 16];
+//     it runs on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains, the 1e-5 logit bar needs fp32):
+//     M-tile = 16 board positions, N = the 16 output channels, K = 4 input channels of one tap;
+//   * the conv input lives in LDS as [42 x 12 padded positions][16 channels]; the A fragment of the
+//     four K-steps of one tap is ONE ds_read_b128 (the K order inside a tap is permuted so that a
+//     lane's four channels are contiguous; the weights are packed on the host in the same order);
+//   * the layer's whole B operand (144 x 16 weights) sits in 36 VGPRs per lane;
+//   * the residual stream never leaves registers (each wave owns 6-7 M-tiles in MFMA C/D layout);
+//   * eval-mode batch norms are folded on the host (nets.py prepare()): per-channel scale/shift
+//     before the first conv of a block, a bias after it;
+//   * two LDS activation buffers (64.5 KB) -> two boards per CU, 2 waves per SIMD.
+// Per board: 20 layers x 25 tiles x 36 MFMAs = 18 000 MFMAs = 36.9 MFLOP; HBM traffic is the
+// 1.6 KB board in, 1.6 KB out and the 188 KB of packed weights (L2-resident, shared by all boards).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "trl_internal.h"
+
+namespace {
+
+constexpr int F = 16;
+constexpr int PW = 12, PH = 42;                 // padded activation plane (1-cell zero border)
+constexpr int STRIDE = 16;                      // floats per position
+constexpr int BUF_FLOATS = PW * PH * STRIDE;    // 8064
+constexpr int BW = 14, BH = 44;                 // padded input board (2-cell border) for the 5x5 conv
+constexpr int NT = 25;                          // M-tiles of 16 positions
+constexpr int WBLOCK = 16 + 16 + 2304 + 16 + 2304;   // packed floats per residual block
+constexpr int TRUNK_THREADS = 256;
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// one 3x3 conv over the tiles of this wave: acc[s] (+)= conv(buf)[tile s]
+template <bool INIT_BIAS>
+__device__ __forceinline__ void conv3x3(const float *buf, const float *wp, float bias, const int (&base)[7], int ntiles,
+                                        int g, int lane, f32x4 (&acc)[7]) {
+    float w[36];
+#pragma unroll
+    for (int i = 0; i < 36; i++) w[i] = wp[i * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < 7; s++) {
+        if (INIT_BIAS) acc[s] = f32x4{bias, bias, bias, bias};
+        else acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // tiles in pairs: two independent accumulator chains hide the 40-cycle dependent MFMA latency
+#pragma unroll
+    for (int s = 0; s < 6; s += 2) {
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int off = ((tap / 3) * PW + (tap % 3)) * STRIDE + 4 * g;
+            f32x4 a0 = *reinterpret_cast<const f32x4 *>(buf + base[s] + off);
+            f32x4 a1 = *reinterpret_cast<const f32x4 *>(buf + base[s + 1] + off);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], w[tap * 4 + j], acc[s], 0, 0, 0);
+                acc[s + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], w[tap * 4 + j], acc[s + 1], 0, 0, 0);
+            }
+        }
+    }
+    if (ntiles == 7) {
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int off = ((tap / 3) * PW + (tap % 3)) * STRIDE + 4 * g;
+            f32x4 a0 = *reinterpret_cast<const f32x4 *>(buf + base[6] + off);
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], w[tap * 4 + j], acc[6], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(TRUNK_THREADS, 2) void k_trunk16(const float *__restrict__ boards, const float *__restrict__ wts,
+                                                              int n_blocks, float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF_FLOATS + BW * BH];
+    float *bufA = lds, *bufB = lds + BUF_FLOATS, *brd = lds + 2 * BUF_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, co = lane & 15;
+    const size_t board = blockIdx.x;
+
+    for (int i = tid; i < 2 * BUF_FLOATS + BW * BH; i += TRUNK_THREADS) lds[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < 400; i += TRUNK_THREADS) brd[(i / 10 + 2) * BW + (i % 10) + 2] = boards[board * 400 + i];
+    __syncthreads();
+
+    // tiles of this wave: T = wave + 4 s.  A-operand row of a lane: position 16 T + (lane & 15);
+    // C/D rows of a lane: positions 16 T + 4 g + r, r = 0..3, column = output channel `co`.
+    const int ntiles = (wave == 0) ? 7 : 6;
+    int base[7];                    // float offset of the 3x3 window's top-left in a padded buffer (A operand)
+#pragma unroll
+    for (int s = 0; s < 7; s++) {
+        int T = wave + 4 * s; if (T >= NT) T = NT - 1;
+        int p = 16 * T + (lane & 15);
+        base[s] = ((p / 10) * PW + (p % 10)) * STRIDE;
+    }
+
+    // conv1: 5x5, one input channel, on the vector ALU (0.9 % of the FLOPs), straight into C/D layout
+    f32x4 x[7];
+    {
+        float w1[25];
+#pragma unroll
+        for (int i = 0; i < 25; i++) w1[i] = wts[co * 25 + i];
+#pragma unroll
+        for (int s = 0; s < 7; s++) {
+            int T = wave + 4 * s; if (T >= NT) T = NT - 1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int p = 16 * T + 4 * g + r, py = p / 10, px = p % 10;
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < 25; k++) a = fmaf(w1[k], brd[(py + k / 5) * BW + px + (k % 5)], a);
+                x[s][r] = a;
+            }
+        }
+    }
+
+    const float *wb = wts + 400;
+    f32x4 acc[7];
+    for (int b = 0; b < n_blocks; b++, wb += WBLOCK) {
+        const float s1 = wb[co], t1 = wb[16 + co], bias_a = wb[32 + 2304 + co];
+        // H1 = relu(bn1(x)) -> buffer A (own positions)
+#pragma unroll
+        for (int s = 0; s < 7; s++) {
+            int T = wave + 4 * s;
+            if (T < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int p = 16 * T + 4 * g + r;
+                    bufA[((p / 10 + 1) * PW + (p % 10) + 1) * STRIDE + co] = fmaxf(fmaf(x[s][r], s1, t1), 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        conv3x3<true>(bufA, wb + 32, bias_a, base, ntiles, g, lane, acc);
+#pragma unroll
+        for (int s = 0; s < 7; s++) {
+            int T = wave + 4 * s;
+            if (T < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int p = 16 * T + 4 * g + r;
+                    bufB[((p / 10 + 1) * PW + (p % 10) + 1) * STRIDE + co] = fmaxf(acc[s][r], 0.f);
+                }
+            }
+        }
+        __syncthreads();
+        conv3x3<false>(bufB, wb + 32 + 2304 + 16, 0.f, base, ntiles, g, lane, acc);
+#pragma unroll
+        for (int s = 0; s < 7; s++) x[s] += acc[s];
+    }
+
+    // tail: relu(bn(x)) -> 1x1 conv over the 16 channels (= 16 lanes) -> folded bn -> relu
+    const float s = wb[co], t = wb[16 + co], wk = wb[32 + co], bk = wb[48];
+#pragma unroll
+    for (int sidx = 0; sidx < 7; sidx++) {
+        int T = wave + 4 * sidx;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float v = fmaxf(fmaf(x[sidx][r], s, t), 0.f) * wk;
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            if (co == 0 && T < NT) out[board * 400 + 16 * T + 4 * g + r] = fmaxf(v + bk, 0.f);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// process_grid of AlphaSame (architectures.py:121-127) for filters = 16, kernels = 1.
+// boards: device float[n_boards][400]; packed: device float[400 + n_blocks * 4656 + 49] in the layout
+// nets.AlphaSame.prepare() builds; out: device float[n_boards][400]; stream: hipStream_t.
+int trl_alphasame_trunk16(const float *dev_boards, int n_boards, const float *dev_packed, int n_blocks,
+                          float *dev_out, void *stream) {
+    if (!dev_boards || !dev_packed || !dev_out || n_boards <= 0 || n_blocks < 0)
+        return fail(TRL_E_INVALID, "trl_alphasame_trunk16: %s", "bad argument");
+    hipLaunchKernelGGL(k_trunk16, dim3(n_boards), dim3(TRUNK_THREADS), 0, (hipStream_t)stream, dev_boards, dev_packed,
+                       n_blocks, dev_out);
+    HIPCHK(hipGetLastError());
+    return TRL_OK;
+}
+
+}  // extern "C"

@@ -72,6 +72,7 @@ class AlphaSame(nn.Module):
                                          "1": nn.BatchNorm1d(mc.value_head_neurons),
                                          "3": nn.Linear(mc.value_head_neurons, 1)})
         self._folded = None
+        self.use_hip_trunk = True       # fused HIP tower when the net is on the GPU and filters == 16
         self.eval()
 
     # -- folding ------------------------------------------------------------------------------
@@ -93,8 +94,29 @@ class AlphaSame(nn.Module):
         fd["oside"] = ((self.osidedense["0"].weight * so.view(-1, 1)).contiguous(), (self.osidedense["0"].bias * so + to).contiguous())
         sv, tv = _affine(self.value_head["1"])
         fd["v0"] = ((self.value_head["0"].weight * sv.view(-1, 1)).contiguous(), (self.value_head["0"].bias * sv + tv).contiguous())
+        fd["packed16"] = self._pack16(fd) if (self.model_config.filters == 16 and self.conv1.weight.is_cuda) else None
         self._folded = fd
         return self
+
+    def _pack16(self, fd):
+        """weights in the layout of csrc/trl_net.hip (B operands of v_mfma_f32_16x16x4_f32)"""
+        lane = torch.arange(64, device=self.conv1.weight.device)
+        co, g = lane & 15, lane >> 4
+
+        def pack_conv(w):                       # w [16 out, 16 in, 3, 3] -> [9 taps][4 j][64 lanes]
+            w = w.reshape(16, 16, 9)
+            out = torch.empty((9, 4, 64), dtype=torch.float32, device=w.device)
+            for j in range(4):
+                out[:, j, :] = w[co, 4 * g + j, :].transpose(0, 1)
+            return out.reshape(-1)
+
+        parts = [self.conv1.weight.reshape(16, 25).reshape(-1)]
+        for s1, t1, wa, ba, wb in fd["blocks"]:
+            parts += [s1.reshape(-1), t1.reshape(-1), pack_conv(wa), ba.reshape(-1), pack_conv(wb)]
+        s, t = fd["tail"]
+        wk, bk = fd["k1"]
+        parts += [s.reshape(-1), t.reshape(-1), wk.reshape(-1), bk.reshape(-1), torch.zeros(15, device=bk.device)]
+        return torch.cat([p.to(torch.float32) for p in parts]).contiguous()
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
@@ -111,6 +133,8 @@ class AlphaSame(nn.Module):
     def trunk(self, boards):
         """boards float[m, 1, 40, 10] -> float[m, 400] (process_grid of the reference, architectures.py:121-127)"""
         fd = self._folded or self.prepare()._folded
+        if fd["packed16"] is not None and self.use_hip_trunk:
+            return self._trunk_hip(boards, fd["packed16"])
         x = F.conv2d(boards, self.conv1.weight, padding=2)
         for s1, t1, wa, ba, wb in fd["blocks"]:
             h = torch.relu(x * s1 + t1)
@@ -119,6 +143,19 @@ class AlphaSame(nn.Module):
         s, t = fd["tail"]
         wk, bk = fd["k1"]
         return torch.relu(F.conv2d(torch.relu(x * s + t), wk, bk)).flatten(1)
+
+    def _trunk_hip(self, boards, packed):
+        """fused HIP tower (csrc/trl_net.hip) on the current stream; raises if the library is missing"""
+        from . import engine as _eng
+        L = _eng.load_library()
+        m = boards.shape[0]
+        x = boards.reshape(m, ROWS * COLS).contiguous()
+        out = torch.empty((m, ROWS * COLS), dtype=torch.float32, device=boards.device)
+        rc = L.trl_alphasame_trunk16(x.data_ptr(), m, packed.data_ptr(), len(self.res_blocks), out.data_ptr(),
+                                     torch.cuda.current_stream(boards.device).cuda_stream)
+        if rc != 0:
+            raise _eng.EngineError("trl_alphasame_trunk16 failed: %s" % L.trl_last_error().decode())
+        return out
 
     @torch.no_grad()
     def heads(self, grids, vec):
