@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""bench.py -- env-steps/s of the fused HIP env-step kernel on BASELINE.json's C2 workload.
+"""bench.py -- env-steps/s (BASELINE.json C2) and MCTS moves/s (C3) of the HIP rollout engine.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -14,6 +14,11 @@ seed 20260630) and resident in HBM before the timed region.
 Multi-GPU: games are independent, so each rank owns its own 4096 games with disjoint RNG
 streams (weak scaling) and there is no data-path collective; torch.distributed (RCCL) only
 provides the barrier and the max-over-ranks reduction of the elapsed time.
+
+The same run then measures BASELINE.json's C3: 1024 concurrent self-play games per GPU, GPU-resident
+MCTS at MAX_ITER=160 (training=True: playout-cap randomisation, root noise, temperature) with the
+10-block/16-filter AlphaSame net (random init, torch.manual_seed(0)); reported under "mcts" in the
+same JSON line, with the MFMA roofline of the fused residual-tower kernel.
 
 Prints one JSON line on rank 0.
 """
@@ -53,6 +58,117 @@ def cpu_baseline(seconds_target=15.0):
                       % (games2 - 1, steps, dt)}
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 matrix peak (v_mfma_f32_16x16x4_f32)
+TRUNK_FLOP_PER_BOARD = 2 * 400 * (25 * 16 + 20 * 144 * 16 + 16)     # conv5x5 + 20 conv3x3 + conv1x1 = 37.2 MFLOP
+
+
+def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
+    """C3: moves/s of the GPU search with the AlphaSame(10,16) evaluator"""
+    import numpy as np
+    import torch
+    import tetris_rl_amd as trl
+    from tetris_rl_amd import parallel
+    n = args.mcts_games
+    torch.manual_seed(0)
+    net = trl.AlphaSame(trl.AlphaSameConfig(blocks=10, filters=16))
+    cfg = trl.Config(visual=False, model="pytorch", model_config=trl.AlphaSameConfig(blocks=10, filters=16),
+                     MAX_ITER=160, training=True)
+    sp = trl.SelfPlay(cfg, net, n, seed=SEED, device=local_rank, streams=parallel.game_streams(rank, n),
+                      auto_reset=True, use_graph=True, record_capacity=1 << 17)
+    sp.tick(args.mcts_warmup)
+    sp.drain()
+    st0 = sp.stats()
+    barrier()
+    t0 = time.perf_counter()
+    done = 0
+    while done < args.mcts_ticks:
+        k = min(512, args.mcts_ticks - done)
+        sp.tick(k)
+        done += k
+        sp.drain()                                     # records leave the device inside the timed region
+    sp.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st1 = sp.stats()
+    if st1["overflow"] or st1["records_dropped"]:
+        raise SystemExit("tree / record capacity overflowed during the MCTS benchmark: results invalid")
+    moves = st1["moves"] - st0["moves"]
+    sims = st1["simulations"] - st0["simulations"]
+    # live timing of the dominant kernel (fused tower) with events on the stream it runs on
+    boards = sp.grids.reshape(2 * n, 1, 40, 10)
+    with torch.cuda.stream(sp.stream):
+        sp.net.trunk(boards)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        e0.record(sp.stream)
+        for _ in range(reps):
+            sp.net.trunk(boards)
+        e1.record(sp.stream)
+    e1.synchronize()
+    trunk_ms = e0.elapsed_time(e1) / reps
+    elapsed, moves_total = parallel.reduce_job(elapsed, moves, dist, dev)
+    _, sims_total = parallel.reduce_job(elapsed, sims, dist, dev)
+    tflops = TRUNK_FLOP_PER_BOARD * 2 * n / (trunk_ms * 1e-3) / 1e12
+    return {
+        "metric": "MCTS moves/sec at MAX_ITER=160 (GPU search + AlphaSame(10,16) fp32)",
+        "value": round(moves_total / elapsed, 1), "unit": "moves/s",
+        "simulations_per_sec": round(sims_total / elapsed, 1),
+        "ms_per_tick": round(elapsed * 1e3 / args.mcts_ticks, 4),
+        "config": {"workload": "C3: %d concurrent self-play games per GPU, MAX_ITER=160, training=True "
+                               "(playout cap 400/80, root noise, temperature), AlphaSame blocks=10 filters=16 random init"
+                               % n, "games_per_gpu": n, "ticks_timed": args.mcts_ticks, "moves_timed": moves_total,
+                   "simulations_timed": sims_total},
+        "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "kernel": "k_trunk16",
+                     "kernel_ms": round(trunk_ms, 4), "flop_per_board": TRUNK_FLOP_PER_BOARD, "boards_per_launch": 2 * n},
+    }
+
+
+def cpu_baseline_mcts(seconds_target=12.0):
+    """oracle search (C) + the stub evaluator is not the C3 workload; the honest CPU statement of C3 is
+    the oracle's play_game with the same net on PyTorch-CPU.  One game slot, one thread, bounded sample."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as op
+    import tetris_rl_amd as trl
+    torch.manual_seed(0)
+    net = trl.AlphaSame(trl.AlphaSameConfig(blocks=10, filters=16)).prepare()
+    torch.set_num_threads(1)
+    L = op.lib()
+    EVAL = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p)
+    state = np.zeros(320, dtype=np.uint8)
+    from tetris_rl_amd import records
+
+    def ev(gptr, vptr, pptr, ctx):
+        L.to_export(gptr, state.ctypes.data)
+        x = records.game_to_x(state)
+        grids = np.stack([x[0].reshape(-1), x[5].reshape(-1)])[:, None, :]
+        vec = np.concatenate([x[1].reshape(-1), [x[2], x[3], x[4]], x[6].reshape(-1), [x[7], x[8], x[9]], [x[10]]])[None].astype(np.float32)
+        v, p = net.evaluate_packed(torch.from_numpy(grids), torch.from_numpy(vec))
+        vptr[0] = float(v[0])
+        C.memmove(pptr, p.numpy().ctypes.data, 11583 * 4)
+
+    cb = EVAL(ev)
+    L.to_mcts.argtypes = [C.c_void_p, C.POINTER(op.MctsConfig), EVAL, C.c_void_p, C.POINTER(op.MctsResult)]
+    g = op.OracleGame(ruleset=2, seed=SEED, stream=0)
+    cfg = op.default_mcts_config(max_iter=160, training=1)
+    res = op.MctsResult()
+    t0 = time.perf_counter()
+    moves = sims = 0
+    while time.perf_counter() - t0 < seconds_target and not g.is_terminal():
+        L.to_mcts(g._buf, C.byref(cfg), cb, None, C.byref(res))
+        g.make_move(res.move)
+        moves += 1
+        sims += res.max_iterations
+    dt = time.perf_counter() - t0
+    return {"value": round(moves / dt, 3), "unit": "moves/s", "cores": 1, "kind": "port",
+            "simulations_per_sec": round(sims / dt, 1),
+            "sample": "oracle search (C) + same AlphaSame(10,16) on PyTorch-CPU 1 thread, game stream 0, %d moves / %d simulations in %.1f s"
+                      % (moves, sims, dt)}
+
+
 def load_pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), if present."""
     path = os.path.join(ROOT, "profiles", "r01_env_rollout_pmc.json")
@@ -70,6 +186,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--games", type=int, default=GAMES_PER_GPU, help="games per GPU (C2: 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-mcts", action="store_true", help="skip the C3 (MCTS moves/s) measurement")
+    ap.add_argument("--mcts-games", type=int, default=1024, help="concurrent self-play games per GPU (C3: 1024)")
+    ap.add_argument("--mcts-ticks", type=int, default=3200, help="timed search ticks (3200 = 20 moves/game at 160 sims)")
+    ap.add_argument("--mcts-warmup", type=int, default=200)
     args = ap.parse_args()
 
     import numpy as np
@@ -119,6 +239,8 @@ def main():
 
     elapsed, steps_total = parallel.reduce_job(elapsed, steps_done, dist, dev)
     kernel_ms, _ = parallel.reduce_job(kernel_ms, 0, dist, dev)
+    eng.close()
+    mcts = None if args.no_mcts else bench_mcts(args, rank, local_rank, world, dist, dev, barrier)
 
     if rank == 0:
         value = steps_total / elapsed
@@ -151,8 +273,12 @@ def main():
                          "algorithmic_bytes_per_step": BYTES_PER_STEP,
                          "note": "integer/latency-bound search; HBM is nominal (SURVEY 8d)"},
         }
+        if mcts is not None:
+            out["mcts"] = mcts
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+            if mcts is not None:
+                out["mcts"]["cpu_baseline"] = cpu_baseline_mcts()
         print(json.dumps(out), flush=True)
 
     if dist is not None:

@@ -53,7 +53,7 @@ struct DevMcts {
     uint16_t *leaf_moves;       // [n_games][TRL_MAX_LEGAL]
     trl_record *recs;
     unsigned int *rec_count;
-    unsigned long long *counters;   // 0 simulations, 1 moves, 2 games, 3 dropped, 4 max nodes, 5 overflow
+    unsigned long long *counters;   // 0 simulations, 1 moves, 2 games, 3 dropped, 4 max nodes, 5 overflow, 6 ticks
 };
 
 // ---- random draws of the search -----------------------------------------------------------------
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
         __syncthreads();
         copy_state(real + slot, &sh.g, tid);
     }
-    if (tid == 0) M.ctl[slot] = sh.ctl;
+    if (tid == 0) { M.ctl[slot] = sh.ctl; if (slot == 0) atomicAdd(&M.counters[6], 1ull); }
 }
 
 // gather of the current leaf states (tests / host-side evaluators)
@@ -647,7 +647,7 @@ int trl_mcts_get_stats(trl_engine *h, trl_mcts_stats *out) {
     unsigned long long c[8];
     HIPCHK(hipMemcpyAsync(c, h->mcts->d.counters, sizeof c, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    out->ticks = h->mcts->ticks; out->simulations = c[0]; out->moves = c[1]; out->games = c[2];
+    out->ticks = c[6]; out->simulations = c[0]; out->moves = c[1]; out->games = c[2];
     out->records_dropped = c[3]; out->max_nodes_used = (uint32_t)c[4]; out->overflow = (uint32_t)c[5];
     return TRL_OK;
 }
