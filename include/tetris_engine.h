@@ -262,6 +262,14 @@ int  trl_mcts_select(trl_engine *h, float *dev_grids, float *dev_vec);
 /* tick part B.  dev_values: float[n_games] (sigmoid value head), dev_policy: float[n_games][11583]
  * softmaxed policy, both as evaluate() returns them (ai.py:1222-1319). */
 int  trl_mcts_expand(trl_engine *h, const float *dev_values, const float *dev_policy);
+/* tick part B without the 11 583-wide policy row: dev_feats float[n_games][feat_dim] is the input of
+ * the policy head (521 for AlphaSame, architectures.py:101-111), dev_head_weight float[11583][feat_dim]
+ * and dev_head_bias float[11583] the head (policy_head.weight / .bias).  Only the logits of the legal
+ * moves are formed and p_i = exp(l_i - max over the legal moves) replaces the full softmax: the softmax
+ * denominator cancels in the root temperature (ai.py:428-434) and in the normalisation over the legal
+ * moves (ai.py:436-443), so the priors are the same up to float32 rounding (~1e-7 relative). */
+int  trl_mcts_expand_head(trl_engine *h, const float *dev_values, const float *dev_feats, int feat_dim,
+                          const float *dev_head_weight, const float *dev_head_bias);
 /* copy out and clear the pending records (host buffer of `cap` records); returns the count in *n_out */
 int  trl_mcts_drain_records(trl_engine *h, trl_record *host_out, int cap, int *n_out);
 int  trl_mcts_get_stats(trl_engine *h, trl_mcts_stats *host_out);

@@ -126,3 +126,33 @@ def test_fused_hip_tower_matches_torch_tower(golden_dir):
     assert a.shape == b.shape == (m, 400)
     assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
     assert float(b.abs().max()) > 0.01
+
+
+def test_legal_only_policy_head_matches_full_softmax_path():
+    """trl_mcts_expand_head (logits of the legal moves only, formed in the expand kernel) against the
+    reference data flow (softmax over all 11 583 logits, then gather): same root children, priors equal
+    to float32 rounding, and the same first move after a whole search."""
+    torch.manual_seed(0)
+    net = trl.AlphaSame(trl.AlphaSameConfig(blocks=10, filters=16))
+    cfg = trl.Config(visual=False, model="pytorch", model_config=trl.AlphaSameConfig(blocks=10, filters=16), MAX_ITER=32,
+                     training=False)
+    res = {}
+    for mode in ("full", "legal"):
+        sp = trl.SelfPlay(cfg, net, 64, seed=9, auto_reset=False, policy_head=mode, use_graph=False)
+        sp.tick(1)
+        sp.synchronize()
+        c, m, v, q, p = sp.engine.mcts_root_children()
+        sp.tick(31)
+        rec = sp.drain()
+        rec = rec[np.argsort(rec["slot"], kind="stable")]
+        res[mode] = (c, m, p, rec)
+    c0, m0, p0, r0 = res["full"]
+    c1, m1, p1, r1 = res["legal"]
+    assert np.array_equal(c0, c1)
+    for g in range(64):
+        n = c0[g]
+        assert np.array_equal(m0[g, :n], m1[g, :n])
+        assert np.allclose(p0[g, :n], p1[g, :n], rtol=2e-5, atol=1e-9)
+    assert len(r0) == len(r1) == 64
+    same = int((r0["chosen"] == r1["chosen"]).sum())
+    assert same >= 60, "searches diverged in %d of 64 slots" % (64 - same)

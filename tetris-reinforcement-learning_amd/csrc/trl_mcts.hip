@@ -285,7 +285,14 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
 }
 
 // ---- tick part B --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *real, const float *values, const float *policy) {
+// HEAD = false: `policy` is the softmaxed 11 583-vector of every leaf (evaluate(), ai.py:1222-1319).
+// HEAD = true : `policy` is the 521-feature vector of every leaf and (head_w, head_b) the policy
+//               head; only the logits of the legal moves are formed (one wavefront per move, the
+//               weight row read coalesced), p_i = exp(l_i - max_legal).  The softmax denominator
+//               cancels in every use the search makes of the priors (ai.py:428-443).
+template <bool HEAD>
+__global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *real, const float *values, const float *policy,
+                                                  const float *head_w, const float *head_b, int feat_dim) {
     __shared__ ExpandShared sh;
     const int tid = threadIdx.x, slot = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t nb = (size_t)slot * M.max_nodes;
@@ -304,14 +311,45 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
         const int first = sh.ctl.n_nodes;
         if (first + n > M.max_nodes) { n = 0; if (tid == 0) { sh.ctl.overflow = 1; atomicAdd(&M.counters[5], 1ull); } }
         const uint16_t *lm = M.leaf_moves + (size_t)slot * TRL_MAX_LEGAL;
-        const float *pol = policy + (size_t)slot * TRL_POLICY_SIZE;
         float mymax = 0.f;
-        for (int k = tid; k < n; k += BLOCK) {
-            int m = lm[k];
-            float p = pol[(TRL_MOVE_PLANE(m) * TRL_POLICY_ROWS + TRL_MOVE_ROW(m)) * TRL_POLICY_COLS + TRL_MOVE_COL(m)];
-            if (p <= 0.f) p = 1e-25f;                                          // ai.py:411
-            sh.pf[k] = p;
-            mymax = fmaxf(mymax, p);
+        if (HEAD) {
+            const float *xf = policy + (size_t)slot * feat_dim;
+            float xr[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) xr[i] = (lane + 64 * i < feat_dim) ? xf[lane + 64 * i] : 0.f;
+            float lmax = -INFINITY;
+            for (int k = wave; k < n; k += BLOCK / 64) {
+                int m = lm[k];
+                int idx = (TRL_MOVE_PLANE(m) * TRL_POLICY_ROWS + TRL_MOVE_ROW(m)) * TRL_POLICY_COLS + TRL_MOVE_COL(m);
+                const float *row = head_w + (size_t)idx * feat_dim;
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < 9; i++) if (lane + 64 * i < feat_dim) a = fmaf(row[lane + 64 * i], xr[i], a);
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+                a += head_b[idx];
+                if (lane == 0) sh.pf[k] = a;
+                lmax = fmaxf(lmax, a);
+            }
+            if (lane == 0) sh.red_f[wave] = lmax;
+            __syncthreads();
+            lmax = fmaxf(sh.red_f[0], sh.red_f[1]);
+            __syncthreads();
+            for (int k = tid; k < n; k += BLOCK) {
+                float p = expf(sh.pf[k] - lmax);
+                if (p <= 0.f) p = 1e-25f;
+                sh.pf[k] = p;
+                mymax = fmaxf(mymax, p);
+            }
+        } else {
+            const float *pol = policy + (size_t)slot * TRL_POLICY_SIZE;
+            for (int k = tid; k < n; k += BLOCK) {
+                int m = lm[k];
+                float p = pol[(TRL_MOVE_PLANE(m) * TRL_POLICY_ROWS + TRL_MOVE_ROW(m)) * TRL_POLICY_COLS + TRL_MOVE_COL(m)];
+                if (p <= 0.f) p = 1e-25f;                                          // ai.py:411
+                sh.pf[k] = p;
+                mymax = fmaxf(mymax, p);
+            }
         }
         const bool root_soft = (leaf == 0) && cfg.use_root_softmax;
         if (root_soft) {                                                       // ai.py:428-434
@@ -619,7 +657,20 @@ int trl_mcts_select(trl_engine *h, float *dev_grids, float *dev_vec) {
 int trl_mcts_expand(trl_engine *h, const float *dev_values, const float *dev_policy) {
     if (!h || !h->mcts || !dev_values || !dev_policy) return fail(TRL_E_INVALID, "trl_mcts_expand: %s", "null argument / no search attached");
     HIPCHK(hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(k_expand, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_values, dev_policy);
+    hipLaunchKernelGGL(k_expand<false>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_values,
+                       dev_policy, (const float *)nullptr, (const float *)nullptr, 0);
+    HIPCHK(hipGetLastError());
+    h->mcts->ticks++;
+    return TRL_OK;
+}
+
+int trl_mcts_expand_head(trl_engine *h, const float *dev_values, const float *dev_feats, int feat_dim,
+                         const float *dev_head_weight, const float *dev_head_bias) {
+    if (!h || !h->mcts || !dev_values || !dev_feats || !dev_head_weight || !dev_head_bias || feat_dim <= 0 || feat_dim > 576)
+        return fail(TRL_E_INVALID, "trl_mcts_expand_head: %s", "bad argument / no search attached");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_expand<true>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_values,
+                       dev_feats, dev_head_weight, dev_head_bias, feat_dim);
     HIPCHK(hipGetLastError());
     h->mcts->ticks++;
     return TRL_OK;

@@ -21,7 +21,7 @@ ABI_SYMBOLS = [
     "trl_env_reset", "trl_env_get_state", "trl_env_set_state", "trl_env_state_dev",
     "trl_env_legal_moves", "trl_env_legal_dev", "trl_env_step", "trl_env_step_dev",
     "trl_env_rollout_random", "trl_last_kernel_ms",
-    "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_drain_records", "trl_mcts_get_stats",
+    "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_expand_head", "trl_mcts_drain_records", "trl_mcts_get_stats",
     "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16",
 ]
 
@@ -113,6 +113,7 @@ def load_library(path=None):
     L.trl_mcts_create.argtypes = [C.c_void_p, C.POINTER(TrlMctsConfig)]
     L.trl_mcts_select.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.trl_mcts_expand.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.trl_mcts_expand_head.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.trl_mcts_drain_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.trl_mcts_get_stats.argtypes = [C.c_void_p, C.POINTER(TrlMctsStats)]
     L.trl_mcts_leaf_states.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -226,6 +227,10 @@ class Engine:
 
     def mcts_expand(self, values_ptr, policy_ptr):
         _check(self._L, self._L.trl_mcts_expand(self._h, values_ptr, policy_ptr), "trl_mcts_expand")
+
+    def mcts_expand_head(self, values_ptr, feats_ptr, feat_dim, weight_ptr, bias_ptr):
+        _check(self._L, self._L.trl_mcts_expand_head(self._h, values_ptr, feats_ptr, int(feat_dim), weight_ptr, bias_ptr),
+               "trl_mcts_expand_head")
 
     def mcts_drain_records(self):
         buf = np.empty(self._rec_cap, dtype=RECORD_DTYPE)

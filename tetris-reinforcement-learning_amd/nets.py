@@ -158,18 +158,30 @@ class AlphaSame(nn.Module):
         return out
 
     @torch.no_grad()
-    def heads(self, grids, vec):
-        """-> (value_pre_activation [n], policy logits [n, 11583])"""
+    def head_inputs(self, grids, vec):
+        """-> (value [n] before the output activation, x [n, 521] = input of the policy head)"""
         fd = self._folded or self.prepare()._folded
         n = vec.shape[0]
         z = self.trunk(grids.reshape(2 * n, 1, ROWS, COLS))
         wo, bo = fd["oside"]
         o = torch.relu(F.linear(z[n:], wo, bo))
         # concat order of the reference (architectures.py:132-140)
-        x = torch.cat([z[:n], vec[:, :52], o, vec[:, 52:]], dim=1)
+        x = torch.cat([z[:n], vec[:, :52], o, vec[:, 52:]], dim=1).contiguous()
         wv, bv = fd["v0"]
-        v = F.linear(torch.relu(F.linear(x, wv, bv)), self.value_head["3"].weight, self.value_head["3"].bias)
-        return v.reshape(n), F.linear(x, self.policy_head.weight, self.policy_head.bias)
+        v = F.linear(torch.relu(F.linear(x, wv, bv)), self.value_head["3"].weight, self.value_head["3"].bias).reshape(n)
+        return v, x
+
+    @torch.no_grad()
+    def heads(self, grids, vec):
+        """-> (value_pre_activation [n], policy logits [n, 11583])"""
+        v, x = self.head_inputs(grids, vec)
+        return v, F.linear(x, self.policy_head.weight, self.policy_head.bias)
+
+    @torch.no_grad()
+    def evaluate_head_inputs(self, grids, vec):
+        """(value [n], x [n, 521]) for trl_mcts_expand_head, which forms only the legal logits itself"""
+        v, x = self.head_inputs(grids, vec)
+        return (torch.tanh(v) if self.use_tanh else torch.sigmoid(v)), x
 
     @torch.no_grad()
     def evaluate_packed(self, grids, vec):

@@ -112,7 +112,12 @@ class SelfPlay:
     """n_slots concurrent self-play games: Engine + net + HIP-graph tick."""
 
     def __init__(self, config, network, n_slots, seed=0, device=0, streams=None, auto_reset=True, use_graph=True,
-                 max_nodes=0, record_capacity=0):
+                 max_nodes=0, record_capacity=0, policy_head="legal"):
+        """policy_head: "legal" = only the legal moves' logits are formed, inside the expand kernel
+        (trl_mcts_expand_head); "full" = the reference's data flow, softmax over all 11 583 logits."""
+        if policy_head not in ("legal", "full"):
+            raise ValueError("policy_head must be 'legal' or 'full'")
+        self.policy_head = policy_head
         import torch
         self.torch = torch
         self.config = config
@@ -137,9 +142,14 @@ class SelfPlay:
     def _tick_body(self):
         e = self.engine
         e.mcts_select(self.grids.data_ptr(), self.vec.data_ptr())
-        v, p = self.net.evaluate_packed(self.grids, self.vec)
-        # v / p live in the stream-ordered allocator (a fixed address inside a captured graph)
-        e.mcts_expand(v.data_ptr(), p.data_ptr())
+        # v / p / x live in the stream-ordered allocator (a fixed address inside a captured graph)
+        if self.policy_head == "full":
+            v, p = self.net.evaluate_packed(self.grids, self.vec)
+            e.mcts_expand(v.data_ptr(), p.data_ptr())
+        else:
+            v, x = self.net.evaluate_head_inputs(self.grids, self.vec)
+            ph = self.net.policy_head
+            e.mcts_expand_head(v.data_ptr(), x.data_ptr(), x.shape[1], ph.weight.data_ptr(), ph.bias.data_ptr())
 
     def _capture(self):
         torch = self.torch
