@@ -172,11 +172,14 @@ def main():
         ("train", dict(training=True)),
         ("train_nosoftmax", dict(training=True, use_root_softmax=False)),
         ("eval_absfpu", dict(training=False, FpuStrategy="absolute", FpuValue=0.4)),
+        ("train_forced", dict(training=True, use_forced_playouts_and_policy_target_pruning=True)),
     ]
     cases = []
     for vi, (name, kw) in enumerate(variants):
         for pi, si in enumerate(picks):
-            if vi >= 2 and pi % 4:
+            if vi in (2, 3) and pi % 4:
+                continue
+            if vi == 4 and pi % 2:
                 continue
             buf = bytes(tr["states"][si])
             kw2 = dict(kw); training = kw2.pop("training")

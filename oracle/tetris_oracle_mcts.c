@@ -285,7 +285,6 @@ int to_mcts(to_game *game, const to_mcts_config *cfg, to_eval_fn eval, void *ctx
     int n = rt->n_children;
     int max_n = 0, max_k = -1;
     for (int k = 0; k < n; k++) { int v = T.nodes[rt->first_child + k].visit_count; if (v >= max_n) { max_n = v; max_k = k; } }
-    (void)max_k;
     int sel = 0;
     double temp = cfg->training ? cfg->temperature : 0.0;
     if (n > 0) {
@@ -306,6 +305,26 @@ int to_mcts(to_game *game, const to_mcts_config *cfg, to_eval_fn eval, void *ctx
             while (lo < hi) { int mid = (lo + hi) / 2; if (x < probs[mid]) hi = mid; else lo = mid + 1; }
             sel = lo;
             free(probs);
+        }
+    }
+    /* policy-target pruning AFTER the move is chosen (ai.py:616-648): visit counts only */
+    if (cfg->use_forced && cfg->training && !fast_iter && n > 0) {
+        mnode *mp = &T.nodes[rt->first_child + max_k];          /* max_id: the LAST child with the largest N */
+        double most = mp->value_avg + cfg->cpuct * mp->policy * sqrt((double)rt->visit_count) / (cfg->dpuct + mp->visit_count);
+        for (int k = 0; k < n; k++) {
+            if (k == max_k) continue;
+            mnode *c = &T.nodes[rt->first_child + k];
+            if (c->visit_count > 0) {
+                double n_forced = sqrt(cfg->c_forced * c->policy * rt->visit_count);
+                int count = 0;
+                for (;;) {
+                    if (c->visit_count == 1) { c->visit_count = 0; break; }
+                    /* the reference puts the ROOT's N in the denominator here (ai.py:640) */
+                    double minus = c->value_avg + cfg->cpuct * c->policy * sqrt((double)rt->visit_count) / (cfg->dpuct + rt->visit_count);
+                    if (count < n_forced && minus < most) { count += 1; c->visit_count -= 1; }
+                    else break;
+                }
+            }
         }
     }
     out->move = n > 0 ? T.nodes[rt->first_child + sel].move : -1;

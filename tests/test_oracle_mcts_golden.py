@@ -13,6 +13,7 @@ VARIANTS = {
     "train": dict(training=1),
     "train_nosoftmax": dict(training=1, use_root_softmax=0),
     "eval_absfpu": dict(training=0, fpu_reduction=0, fpu_value=0.4),
+    "train_forced": dict(training=1, use_forced=1),
 }
 
 

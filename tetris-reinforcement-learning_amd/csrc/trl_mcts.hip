@@ -468,6 +468,32 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
                 }
             }
             sh.chosen = n > 0 ? (int)M.t.move[nb + first + sel] : -1;
+            // policy-target pruning AFTER the move is chosen (ai.py:616-648): only the recorded visit counts change
+            if (cfg.use_forced && cfg.training && !sh.ctl.fast && n > 0) {
+                int max_n = 0, max_k = 0;
+                for (int k = 0; k < n; k++) { int v = M.t.visit[nb + first + k]; if (v >= max_n) { max_n = v; max_k = k; } }   // last maximum
+                const double rootN = (double)M.t.visit[nb], sq = sqrt(rootN);
+                const size_t mi = nb + first + max_k;
+                const double most = M.t.q[mi] + cfg.cpuct * M.t.prior[mi] * sq / (cfg.dpuct + M.t.visit[mi]);
+                for (int k = 0; k < n; k++) {
+                    if (k == max_k) continue;
+                    const size_t ci = nb + first + k;
+                    int vc = M.t.visit[ci];
+                    if (vc > 0) {
+                        const double pk = M.t.prior[ci];
+                        const double n_forced = sqrt(cfg.c_forced * pk * rootN);
+                        // the reference puts the ROOT's N in the denominator (ai.py:640), so the bound is constant
+                        const double minus = M.t.q[ci] + cfg.cpuct * pk * sq / (cfg.dpuct + rootN);
+                        int count = 0;
+                        for (;;) {
+                            if (vc == 1) { vc = 0; break; }
+                            if (count < n_forced && minus < most) { count += 1; vc -= 1; }
+                            else break;
+                        }
+                        M.t.visit[ci] = vc;
+                    }
+                }
+            }
             unsigned int idx = atomicAdd(M.rec_count, 1u);
             sh.rec_idx = idx < (unsigned)M.rec_cap ? (int)idx : -1;
             if (sh.rec_idx < 0) atomicAdd(&M.counters[3], 1ull);
