@@ -13,7 +13,8 @@
 //   * the residual stream never leaves registers (each wave owns 6-7 M-tiles in MFMA C/D layout);
 //   * eval-mode batch norms are folded on the host (nets.py prepare()): per-channel scale/shift
 //     before the first conv of a block, a bias after it;
-//   * two LDS activation buffers (64.5 KB) -> two boards per CU, 2 waves per SIMD.
+//   * ONE LDS activation buffer (32 KB, rewritten in place behind a barrier) -> three boards per CU,
+//     3 waves per SIMD.
 // Per board: 20 layers x 25 tiles x 36 MFMAs = 18 000 MFMAs = 36.9 MFLOP; HBM traffic is the
 // 1.6 KB board in, 1.6 KB out and the 188 KB of packed weights (L2-resident, shared by all boards).
 #include <hip/hip_runtime.h>
@@ -71,15 +72,15 @@ __device__ __forceinline__ void conv3x3(const float *buf, const float *wp, float
     }
 }
 
-__global__ __launch_bounds__(TRUNK_THREADS, 2) void k_trunk16(const float *__restrict__ boards, const float *__restrict__ wts,
+__global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__restrict__ boards, const float *__restrict__ wts,
                                                               int n_blocks, float *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * BUF_FLOATS + BW * BH];
-    float *bufA = lds, *bufB = lds + BUF_FLOATS, *brd = lds + 2 * BUF_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[BUF_FLOATS + BW * BH];
+    float *bufA = lds, *brd = lds + BUF_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, co = lane & 15;
     const size_t board = blockIdx.x;
 
-    for (int i = tid; i < 2 * BUF_FLOATS + BW * BH; i += TRUNK_THREADS) lds[i] = 0.f;
+    for (int i = tid; i < BUF_FLOATS + BW * BH; i += TRUNK_THREADS) lds[i] = 0.f;
     __syncthreads();
     for (int i = tid; i < 400; i += TRUNK_THREADS) brd[(i / 10 + 2) * BW + (i % 10) + 2] = boards[board * 400 + i];
     __syncthreads();
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(TRUNK_THREADS, 2) void k_trunk16(const float *__res
         }
         __syncthreads();
         conv3x3<true>(bufA, wb + 32, bias_a, base, ntiles, g, lane, acc);
+        __syncthreads();                              // every wave has read its halo: the buffer can be overwritten
 #pragma unroll
         for (int s = 0; s < 7; s++) {
             int T = wave + 4 * s;
@@ -140,14 +142,15 @@ __global__ __launch_bounds__(TRUNK_THREADS, 2) void k_trunk16(const float *__res
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     int p = 16 * T + 4 * g + r;
-                    bufB[((p / 10 + 1) * PW + (p % 10) + 1) * STRIDE + co] = fmaxf(acc[s][r], 0.f);
+                    bufA[((p / 10 + 1) * PW + (p % 10) + 1) * STRIDE + co] = fmaxf(acc[s][r], 0.f);
                 }
             }
         }
         __syncthreads();
-        conv3x3<false>(bufB, wb + 32 + 2304 + 16, 0.f, base, ntiles, g, lane, acc);
+        conv3x3<false>(bufA, wb + 32 + 2304 + 16, 0.f, base, ntiles, g, lane, acc);
 #pragma unroll
         for (int s = 0; s < 7; s++) x[s] += acc[s];
+        __syncthreads();
     }
 
     // tail: relu(bn(x)) -> 1x1 conv over the 16 channels (= 16 lanes) -> folded bn -> relu
