@@ -204,15 +204,24 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
     dist = None
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    # one rank per GPU; TRL_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box:
+    # RCCL refuses two ranks on one device)
+    backend = os.environ.get("TRL_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if world > ndev and backend == "nccl":
+        raise SystemExit("%d ranks but %d GPUs" % (world, ndev))
+    local_rank = local_rank % ndev
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank) if backend == "nccl" else None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     n = args.games
     eng = trl.Engine(n, ruleset="s2", seed=SEED, device=local_rank)

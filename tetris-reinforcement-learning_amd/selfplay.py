@@ -251,19 +251,60 @@ def load_best_model(config):
 
 
 # ---- S3 / S4: make_training_set, play_game --------------------------------------------------------------------------
-def _run_games(config, network, num_games, seed, device=0, max_slots=1024, streams=None):
+def _play_raw(config, network, num_games, seed, device=0, max_slots=1024, streams=None):
+    """plays until num_games games have ended; returns the raw device records (RECORD_DTYPE) of
+    exactly those games, in (episode, slot, ply) order"""
     slots = min(int(num_games), int(max_slots))
     sp = SelfPlay(config, network, slots, seed=seed, device=device, streams=streams, auto_reset=num_games > slots)
-    col = GameCollector(config)
-    chunk = 64
-    while len(col.finished) < num_games:
-        sp.tick(chunk)
-        col.add(sp.drain())
+    chunks, ended = [], []
+    while len(ended) < num_games:
+        sp.tick(64)
+        r = sp.drain()
+        chunks.append(r)
+        ended += [(int(e), int(sl)) for e, sl in zip(r["episode"][r["kind"] == _eng.REC_GAME_END], r["slot"][r["kind"] == _eng.REC_GAME_END])]
         st = sp.stats()
         if st["records_dropped"] or st["overflow"]:
             raise _eng.EngineError("device record buffer or tree capacity overflowed: %r" % (st,))
+    recs = np.concatenate(chunks)
+    keep = set(sorted(ended)[:num_games])
+    mask = np.array([(int(e), int(sl)) in keep for e, sl in zip(recs["episode"], recs["slot"])], dtype=bool)
+    recs = recs[mask]
+    return recs[np.lexsort((recs["kind"], recs["ply"], recs["slot"], recs["episode"]))]
+
+
+def games_from_records(config, recs):
+    """raw records (possibly gathered from several ranks) -> finished games in (episode, slot) order"""
+    col = GameCollector(config)
+    col.add(recs)
     col.finished.sort(key=lambda g: (g["key"][1], g["key"][0]))
-    return col.finished[:num_games], sp
+    return col.finished
+
+
+def _run_games(config, network, num_games, seed, device=0, max_slots=1024, streams=None, dist=None):
+    """Single process: all num_games here.  With an initialised torch.distributed group: rank r plays
+    games [r * G/W, (r+1) * G/W) on its own GPU (disjoint RNG streams, no collective during play) and the
+    packed records are gathered to rank 0, which returns all games; other ranks return []."""
+    from . import parallel
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if num_games % world:
+            raise ValueError("num_games must be a multiple of the world size")
+        per = num_games // world
+        recs = _play_raw(config, network, per, seed, device=device, max_slots=max_slots,
+                         streams=parallel.game_streams(rank, min(per, max_slots)))
+        recs = recs.copy()
+        recs["slot"] += np.uint32(rank * max(per, 1))                 # global game id
+        dev = None
+        if dist.get_backend() == "nccl":
+            import torch
+            dev = torch.device("cuda", device)
+        parts = parallel.gather_bytes(np.frombuffer(recs.tobytes(), dtype=np.uint8), dist, dev)
+        if parts is None:
+            return [], None
+        allrecs = np.concatenate([np.frombuffer(p.tobytes(), dtype=_eng.RECORD_DTYPE) for p in parts])
+        return games_from_records(config, allrecs)[:num_games], None
+    recs = _play_raw(config, network, num_games, seed, device=device, max_slots=max_slots, streams=streams)
+    return games_from_records(config, recs)[:num_games], None
 
 
 def play_game(config, interference_network, game_number=None, screen=None, seed=0):
@@ -278,10 +319,14 @@ def play_game(config, interference_network, game_number=None, screen=None, seed=
 
 
 def make_training_set(config, interference_network, num_games, save_game=False, save_stats=True, screen=None, seed=0,
-                      max_slots=1024):
+                      max_slots=1024, device=0, dist=None):
     """ai.py:1809-1845: plays num_games games, optionally writes {data_dir}/{n}.txt and the averaged
-    stats line; returns the records only when save_stats is False (as the reference does)."""
-    games, _ = _run_games(config, interference_network, num_games, seed, max_slots=max_slots)
+    stats line; returns the records only when save_stats is False (as the reference does).
+    `dist`: an initialised torch.distributed module -> games are sharded over the ranks (one GPU each),
+    records gathered to rank 0 over RCCL; files are written by rank 0 only."""
+    games, _ = _run_games(config, interference_network, num_games, seed, max_slots=max_slots, device=device, dist=dist)
+    if dist is not None and dist.is_initialized() and dist.get_rank() != 0:
+        return None
     series_data, series_stats = [], []
     for g in games:
         series_data.extend(g["data"])
