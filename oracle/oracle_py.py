@@ -231,3 +231,15 @@ def play_game_stub(ruleset, seed, stream, cfg, max_log=2048, max_children=2048 *
     return dict(plies=n, winner=winner.value, final=g.export(), ply_state=ply_state[:n], ply_move=ply_move[:n],
                 ply_save=ply_save[:n], ply_nchild=ply_nchild[:n], child_moves=child_moves[:tot],
                 child_visits=child_visits[:tot])
+
+
+def play_battle_stub(ruleset, seed, stream, cfg, side, salt1, salt2, max_log=4096):
+    """one game of the gating match with two salted stub evaluators; returns (moves, winner)"""
+    L = lib()
+    g = OracleGame(ruleset=ruleset, seed=seed, stream=stream)
+    mv = np.zeros(max_log, dtype=np.uint16)
+    w = C.c_int()
+    L.to_play_battle_stub.argtypes = [C.c_void_p, C.POINTER(MctsConfig), C.c_int, C.c_uint64, C.c_uint64, C.c_int,
+                                      C.c_void_p, C.POINTER(C.c_int)]
+    n = L.to_play_battle_stub(g._buf, C.byref(cfg), side, salt1, salt2, max_log, mv.ctypes.data, C.byref(w))
+    return mv[:n].copy(), w.value

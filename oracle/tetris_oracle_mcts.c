@@ -375,6 +375,41 @@ void to_stub_eval(const to_game *g, float *value, float *policy, void *ctx) {
     to_stub_eval_state(&s, value, policy);
 }
 
+/* a second deterministic evaluator for the gating tests: the stub with a salted hash (ctx = &salt) */
+void to_stub_eval_salted(const to_game *g, float *value, float *policy, void *ctx) {
+    trl_game_state s;
+    to_export(g, &s);
+    uint64_t salt = ctx ? *(const uint64_t *)ctx : 0, h = to_stub_hash(&s);
+    if (salt) h = mix64m(h ^ salt);
+    *value = (float)(mix64m(h) >> 40) * (1.0f / 16777216.0f);
+    for (int i = 0; i < TRL_POLICY_SIZE; i++) {
+        uint64_t k = mix64m(h ^ ((uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull));
+        float u = (float)(k >> 40) * (1.0f / 16777216.0f);
+        policy[i] = (k & 15) == 0 ? 0.0f : u * u;
+    }
+}
+
+/* one game of battle_networks / aplay_battle_game (ai.py:2072-2085): evaluator `salt1` plays player `side`,
+ * evaluator `salt2` the other; the searcher's evaluator is used for the whole search.  Returns plies. */
+int to_play_battle_stub(to_game *g, const to_mcts_config *cfg, int side, uint64_t salt1, uint64_t salt2, int max_log,
+                        uint16_t *ply_move, int *winner_out) {
+    int plies = 0, history = 1;
+    to_mcts_result *res = (to_mcts_result *)malloc(sizeof(to_mcts_result));
+    while (!to_is_terminal(g) && history < TRL_MAX_MOVES) {
+        uint64_t salt = ((g->turn == 0) == (side == 0)) ? salt1 : salt2;
+        to_mcts(g, cfg, to_stub_eval_salted, &salt, res);
+        if (res->move < 0) break;
+        if (plies < max_log) ply_move[plies] = (uint16_t)res->move;
+        int mover = g->turn;
+        to_make_move(g, TRL_MOVE_PLANE(res->move), TRL_MOVE_COL(res->move) - 2, TRL_MOVE_ROW(res->move), 1);
+        if (mover == 1 && g->turn == 0) history++;
+        plies++;
+    }
+    *winner_out = to_winner(g);
+    free(res);
+    return plies;
+}
+
 int to_mcts_stub(to_game *game, const to_mcts_config *cfg, to_mcts_result *out) {
     return to_mcts(game, cfg, to_stub_eval, NULL, out);
 }

@@ -16,3 +16,5 @@ from .selfplay import (Config, SelfPlay, GameCollector, play_game, make_training
 from .nets import AlphaSame, AlphaSameConfig  # noqa: F401,E402
 from . import compat  # noqa: F401,E402
 from .compat import Game, get_move_matrix, get_move_list, evaluate, MCTS, search_statistics  # noqa: F401,E402
+from . import gating  # noqa: F401,E402
+from .gating import battle_networks  # noqa: F401,E402

@@ -578,7 +578,7 @@ __global__ void k_root_children(DevMcts M, int32_t *counts, uint16_t *moves, int
 }
 
 // deterministic stub evaluator (tests): same function as oracle/tetris_oracle_mcts.c to_stub_eval_state
-__global__ __launch_bounds__(256) void k_stub_eval(DevMcts M, float *values, float *policy) {
+__global__ __launch_bounds__(256) void k_stub_eval(DevMcts M, float *values, float *policy, uint64_t salt) {
     const int slot = blockIdx.x, tid = threadIdx.x;
     const SlotCtl c = M.ctl[slot];
     const trl_game_state *s = M.pool + (size_t)slot * M.cap_states + (c.phase == 1 ? c.leaf_state : 0);
@@ -593,6 +593,7 @@ __global__ __launch_bounds__(256) void k_stub_eval(DevMcts M, float *values, flo
         h = mix64(h ^ meta);
     }
     h = mix64(h ^ s->turn);
+    if (salt) h = mix64(h ^ salt);
     if (tid == 0) values[slot] = (float)(mix64(h) >> 40) * (1.0f / 16777216.0f);
     for (int i = tid; i < TRL_POLICY_SIZE; i += blockDim.x) {
         uint64_t k = mix64(h ^ ((uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull));
@@ -761,10 +762,15 @@ int trl_mcts_root_children(trl_engine *h, int32_t *counts, uint16_t *moves, int3
 }
 
 // test hook: the stub evaluator on the current leaves (values[n], policy[n][11583], device pointers)
+int trl_debug_stub_eval_salted(trl_engine *h, float *dev_values, float *dev_policy, uint64_t salt);
 int trl_debug_stub_eval(trl_engine *h, float *dev_values, float *dev_policy) {
+    return trl_debug_stub_eval_salted(h, dev_values, dev_policy, 0);
+}
+// salt != 0 gives a different deterministic evaluator ("a second network") for the gating tests
+int trl_debug_stub_eval_salted(trl_engine *h, float *dev_values, float *dev_policy, uint64_t salt) {
     if (!h || !h->mcts) return fail(TRL_E_INVALID, "%s", "no search attached");
     HIPCHK(hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(k_stub_eval, dim3(h->cfg.n_games), dim3(256), 0, h->stream, h->mcts->d, dev_values, dev_policy);
+    hipLaunchKernelGGL(k_stub_eval, dim3(h->cfg.n_games), dim3(256), 0, h->stream, h->mcts->d, dev_values, dev_policy, salt);
     HIPCHK(hipGetLastError());
     return TRL_OK;
 }
