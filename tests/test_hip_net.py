@@ -156,3 +156,41 @@ def test_legal_only_policy_head_matches_full_softmax_path():
     assert len(r0) == len(r1) == 64
     same = int((r0["chosen"] == r1["chosen"]).sum())
     assert same >= 60, "searches diverged in %d of 64 slots" % (64 - same)
+
+
+def test_baseresnet_selfplay_and_wide_policy_head():
+    """the reference's default net family drives the device search; its 853-wide policy-head input
+    (small config) goes through the in-kernel legal-logit path and agrees with the full-softmax path"""
+    torch.manual_seed(2)
+    mc = trl.AuxBaseResNetConfig(blocks=2, filters=8, opp_hidden=16, own_kernels=2, value_hidden=8, aux_hidden=8)
+    net = trl.AuxBaseResNet(mc)
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=16, training=False)
+    res = {}
+    for mode in ("full", "legal"):
+        sp = trl.SelfPlay(cfg, net, 32, seed=4, auto_reset=False, policy_head=mode)
+        sp.tick(1)
+        sp.synchronize()
+        res[mode] = sp.engine.mcts_root_children()
+        sp.tick(15)
+        res[mode + "_rec"] = sp.drain()
+    c0, m0, _, _, p0 = res["full"]
+    c1, m1, _, _, p1 = res["legal"]
+    assert np.array_equal(c0, c1)
+    for g in range(32):
+        assert np.array_equal(m0[g, :c0[g]], m1[g, :c0[g]]) and np.allclose(p0[g, :c0[g]], p1[g, :c0[g]], rtol=2e-5, atol=1e-9)
+    assert len(res["full_rec"]) == len(res["legal_rec"]) == 32
+
+
+def test_c5_configuration_runs():
+    """BASELINE config C5 in miniature: 20-block / 64-filter AlphaSame (PyTorch tower: the fused HIP tower is
+    the 16-filter one), MAX_ITER=800 with forced playouts + policy-target pruning; a few ticks of 32 slots"""
+    torch.manual_seed(0)
+    mc = trl.AlphaSameConfig(blocks=20, filters=64)
+    net = trl.AlphaSame(mc)
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=800, training=True,
+                     use_forced_playouts_and_policy_target_pruning=True)
+    sp = trl.SelfPlay(cfg, net, 32, seed=1)
+    assert sp.net._folded["packed16"] is None
+    sp.tick(24)
+    st = sp.stats()
+    assert st["simulations"] == 24 * 32 and st["overflow"] == 0

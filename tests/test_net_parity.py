@@ -77,3 +77,43 @@ def test_reference_checkpoint_roundtrip(tmp_path, golden_dir):
     b = net2.evaluate_packed(torch.from_numpy(grids), torch.from_numpy(vec))
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     assert abs(float(a[1].sum(dim=1)[0]) - 1.0) < 1e-5
+
+
+def _load_generic(d, tag, net):
+    keys = [str(k) for k in d["%s/keys" % tag]]
+    assert list(net.state_dict().keys()) == keys, "state_dict keys differ from the reference's"
+    head_in = net.policy_head.weight.shape[1]
+    w, b = net_fixture.policy_head(in_features=head_in)
+    sd = {k: (torch.from_numpy(w) if k == "policy_head.weight" else torch.from_numpy(b) if k == "policy_head.bias"
+              else torch.from_numpy(d["%s/%s" % (tag, k)])) for k in keys}
+    net.load_state_dict(sd)
+    return net.prepare()
+
+
+@pytest.mark.parametrize("tag", ["base", "aux"])
+def test_baseresnet_family_matches_reference(golden_dir, tag):
+    """BaseResNet / AuxBaseResNet (the reference's current default family, architectures.py:150-353)"""
+    d = np.load(os.path.join(golden_dir, "net.npz"))
+    small = dict(blocks=2, filters=8, opp_hidden=16, own_kernels=2, value_hidden=8)
+    net = (nets.BaseResNet(nets.BaseResNetConfig(**small)) if tag == "base"
+           else nets.AuxBaseResNet(nets.AuxBaseResNetConfig(aux_hidden=8, **small)))
+    net = _load_generic(d, tag, net)
+    grids, vec = packed_features(d["states"])
+    v, logits = net.heads(torch.from_numpy(grids), torch.from_numpy(vec))
+    assert np.abs(torch.sigmoid(v).numpy() - d["%s/values" % tag]).max() < TOL
+    assert np.abs(logits.numpy() - d["%s/logits" % tag]).max() < TOL
+    if tag == "aux":
+        n = len(d["states"])
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+        out = net(t(grids[0]).reshape(n, 1, 40, 10), t(vec[:, :49]).reshape(n, 7, 7), t(vec[:, 49]), t(vec[:, 50]), t(vec[:, 51]),
+                  t(grids[1]).reshape(n, 1, 40, 10), t(vec[:, 52:101]).reshape(n, 7, 7), t(vec[:, 101]), t(vec[:, 102]),
+                  t(vec[:, 103]), t(vec[:, 104]))
+        assert len(out) == 3 and np.abs(out[2].numpy() - d["aux/aux"]).max() < TOL
+
+
+def test_default_size_nets_have_the_reference_key_layout(golden_dir):
+    d = np.load(os.path.join(golden_dir, "net.npz"))
+    for tag, net in (("base_default", nets.BaseResNet()), ("aux_default", nets.AuxBaseResNet())):
+        sd = net.state_dict()
+        assert list(sd.keys()) == [str(k) for k in d["%s/keys" % tag]]
+        assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in d["%s/shapes" % tag]]

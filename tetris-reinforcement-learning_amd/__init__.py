@@ -13,7 +13,8 @@ def build(force=False, verbose=False):
 from .selfplay import (Config, SelfPlay, GameCollector, play_game, make_training_set, self_play_loop,  # noqa: F401,E402
                        instantiate_network, load_best_model, highest_model_number, highest_data_number, search_options,
                        games_from_records)
-from .nets import AlphaSame, AlphaSameConfig  # noqa: F401,E402
+from .nets import (AlphaSame, AlphaSameConfig, BaseResNet, BaseResNetConfig, AuxBaseResNet,  # noqa: F401,E402
+                   AuxBaseResNetConfig)
 from . import compat  # noqa: F401,E402
 from .compat import Game, get_move_matrix, get_move_list, evaluate, MCTS, search_statistics  # noqa: F401,E402
 from . import gating  # noqa: F401,E402

@@ -26,6 +26,7 @@ namespace {
 
 constexpr int DEFAULT_MAX_NODES = 65536;
 constexpr int DEFAULT_REC_CAP = 16384;
+constexpr int HEAD_MAX_FEATS = 2048;          // widest policy-head input handled in the expand kernel (BaseResNet: 1653)
 
 struct SlotCtl {
     int32_t phase;          // 0 = start a new search at the next select, 1 = searching, 2 = idle (game over, no auto-reset)
@@ -106,6 +107,7 @@ struct ExpandShared {
     SlotCtl ctl;
     float  pf[TRL_MAX_LEGAL];
     double pd[TRL_MAX_LEGAL];
+    float  xs[HEAD_MAX_FEATS];
     float  red_f[2];
     double dsum;
     int    flag, chosen, rec_idx, end_idx;
@@ -314,17 +316,15 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
         float mymax = 0.f;
         if (HEAD) {
             const float *xf = policy + (size_t)slot * feat_dim;
-            float xr[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) xr[i] = (lane + 64 * i < feat_dim) ? xf[lane + 64 * i] : 0.f;
+            for (int i = tid; i < feat_dim; i += BLOCK) sh.xs[i] = xf[i];      // the leaf's feature vector, staged once
+            __syncthreads();
             float lmax = -INFINITY;
             for (int k = wave; k < n; k += BLOCK / 64) {
                 int m = lm[k];
                 int idx = (TRL_MOVE_PLANE(m) * TRL_POLICY_ROWS + TRL_MOVE_ROW(m)) * TRL_POLICY_COLS + TRL_MOVE_COL(m);
                 const float *row = head_w + (size_t)idx * feat_dim;
                 float a = 0.f;
-#pragma unroll
-                for (int i = 0; i < 9; i++) if (lane + 64 * i < feat_dim) a = fmaf(row[lane + 64 * i], xr[i], a);
+                for (int i = lane; i < feat_dim; i += 64) a = fmaf(row[i], sh.xs[i], a);
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
                 a += head_b[idx];
@@ -693,7 +693,7 @@ int trl_mcts_expand(trl_engine *h, const float *dev_values, const float *dev_pol
 
 int trl_mcts_expand_head(trl_engine *h, const float *dev_values, const float *dev_feats, int feat_dim,
                          const float *dev_head_weight, const float *dev_head_bias) {
-    if (!h || !h->mcts || !dev_values || !dev_feats || !dev_head_weight || !dev_head_bias || feat_dim <= 0 || feat_dim > 576)
+    if (!h || !h->mcts || !dev_values || !dev_feats || !dev_head_weight || !dev_head_bias || feat_dim <= 0 || feat_dim > HEAD_MAX_FEATS)
         return fail(TRL_E_INVALID, "trl_mcts_expand_head: %s", "bad argument / no search attached");
     HIPCHK(hipSetDevice(h->cfg.device));
     hipLaunchKernelGGL(k_expand<true>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_values,

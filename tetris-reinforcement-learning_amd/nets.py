@@ -209,3 +209,160 @@ def load_reference_checkpoint(path, model_config=None, device="cpu"):
     sd = torch.load(path, map_location="cpu", weights_only=True)
     net.load_state_dict(sd)
     return net.to(device).prepare()
+
+
+# ---- the reference's current default family (architectures.py:150-353) -------------------------------------
+class BaseResNetConfig:
+    def __init__(self, blocks=8, filters=32, opp_hidden=128, own_kernels=4, value_hidden=16):
+        self.blocks, self.filters, self.opp_hidden = blocks, filters, opp_hidden
+        self.own_kernels, self.value_hidden = own_kernels, value_hidden
+
+
+class AuxBaseResNetConfig(BaseResNetConfig):
+    def __init__(self, aux_hidden=16, aux_weight=1.5, **kw):
+        super().__init__(**kw)
+        self.aux_hidden, self.aux_weight = aux_hidden, aux_weight
+
+
+class _PostBlock(nn.Module):
+    """parameter holder: conv1, bn1, conv2, bn2 (post-activation block, architectures.py:159-170)"""
+
+    def __init__(self, f):
+        super().__init__()
+        self.conv1 = nn.Conv2d(f, f, 3, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(f)
+        self.conv2 = nn.Conv2d(f, f, 3, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(f)
+
+
+def _fold_conv_bn(conv, bn):
+    s, t = _affine(bn)
+    return (conv.weight * s.view(-1, 1, 1, 1)).contiguous(), t.contiguous()
+
+
+def _fold_lin_bn(lin, bn):
+    s, t = _affine(bn)
+    return (lin.weight * s.view(-1, 1)).contiguous(), (lin.bias * s + t).contiguous()
+
+
+class BaseResNet(nn.Module):
+    """Inference module with the reference's parameter names (stem.0/.1, trunk.i.{conv1,bn1,conv2,bn2},
+    opp_collapse, opp_encode, bias_project, own_collapse, policy_head, value_head) and the same packed
+    feature interface as AlphaSame.  Every conv is followed directly by its batch norm, so all norms fold
+    into the convolutions; the tower runs as PyTorch-ROCm convolutions (no fused HIP kernel yet)."""
+
+    has_aux = False
+
+    def __init__(self, model_config=None, use_tanh=False):
+        super().__init__()
+        mc = model_config or BaseResNetConfig()
+        self.model_config, self.use_tanh = mc, use_tanh
+        f = mc.filters
+        self.stem = nn.ModuleDict({"0": nn.Conv2d(1, f, 3, padding=1, bias=False), "1": nn.BatchNorm2d(f)})
+        self.trunk = nn.ModuleList([_PostBlock(f) for _ in range(mc.blocks)])
+        self.opp_collapse = nn.ModuleDict({"0": nn.Conv2d(f, 1, 1, bias=False), "1": nn.BatchNorm2d(1)})
+        opp_in = ROWS * COLS + PIECES_PER_PLAYER + SCALARS_PER_PLAYER
+        self.opp_encode = nn.ModuleDict({"0": nn.Linear(opp_in, mc.opp_hidden), "1": nn.BatchNorm1d(mc.opp_hidden)})
+        self.bias_project = nn.Linear(mc.opp_hidden + PIECES_PER_PLAYER + SCALARS_PER_PLAYER + 1, f)
+        self.own_collapse = nn.ModuleDict({"0": nn.Conv2d(f, mc.own_kernels, 1, bias=False), "1": nn.BatchNorm2d(mc.own_kernels)})
+        head_in = mc.own_kernels * ROWS * COLS + PIECES_PER_PLAYER + SCALARS_PER_PLAYER + 1
+        self.policy_head = nn.Linear(head_in, POLICY_SIZE)
+        self.value_head = nn.ModuleDict({"0": nn.Linear(head_in, mc.value_hidden), "1": nn.BatchNorm1d(mc.value_hidden),
+                                         "3": nn.Linear(mc.value_hidden, 1)})
+        self._folded = None
+        self.eval()
+
+    @torch.no_grad()
+    def prepare(self):
+        fd = {"stem": _fold_conv_bn(self.stem["0"], self.stem["1"]),
+              "blocks": [(_fold_conv_bn(b.conv1, b.bn1), _fold_conv_bn(b.conv2, b.bn2)) for b in self.trunk],
+              "opp": _fold_conv_bn(self.opp_collapse["0"], self.opp_collapse["1"]),
+              "enc": _fold_lin_bn(self.opp_encode["0"], self.opp_encode["1"]),
+              "own": _fold_conv_bn(self.own_collapse["0"], self.own_collapse["1"]),
+              "v0": _fold_lin_bn(self.value_head["0"], self.value_head["1"])}
+        if self.has_aux:
+            fd["a0"] = _fold_lin_bn(self.aux_head["0"], self.aux_head["1"])
+        self._folded = fd
+        return self
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._folded = None
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._folded = None
+        return r
+
+    @torch.no_grad()
+    def head_inputs(self, grids, vec):
+        fd = self._folded or self.prepare()._folded
+        n = vec.shape[0]
+        x = torch.relu(F.conv2d(grids.reshape(2 * n, 1, ROWS, COLS), *fd["stem"], padding=1))
+        for (w1, b1), (w2, b2) in fd["blocks"]:
+            h = torch.relu(F.conv2d(x, w1, b1, padding=1))
+            x = torch.relu(F.conv2d(h, w2, b2, padding=1) + x)
+        a_feat, o_feat = x[:n], x[n:]
+        a_extra, o_extra, color = vec[:, :52], vec[:, 52:104], vec[:, 104:105]
+        o_col = torch.relu(F.conv2d(o_feat, *fd["opp"])).flatten(1)
+        opp_repr = torch.relu(F.linear(torch.cat([o_col, o_extra], dim=1), *fd["enc"]))
+        bias_vec = F.linear(torch.cat([opp_repr, a_extra, color], dim=1), self.bias_project.weight, self.bias_project.bias)
+        flat = torch.relu(F.conv2d(a_feat + bias_vec.view(n, -1, 1, 1), *fd["own"])).flatten(1)
+        hx = torch.cat([flat, a_extra, color], dim=1).contiguous()
+        v = F.linear(torch.relu(F.linear(hx, *fd["v0"])), self.value_head["3"].weight, self.value_head["3"].bias).reshape(n)
+        return v, hx
+
+    @torch.no_grad()
+    def heads(self, grids, vec):
+        v, hx = self.head_inputs(grids, vec)
+        return v, F.linear(hx, self.policy_head.weight, self.policy_head.bias)
+
+    @torch.no_grad()
+    def evaluate_packed(self, grids, vec):
+        v, logits = self.heads(grids, vec)
+        return (torch.tanh(v) if self.use_tanh else torch.sigmoid(v)), torch.softmax(logits, dim=1)
+
+    @torch.no_grad()
+    def evaluate_head_inputs(self, grids, vec):
+        v, hx = self.head_inputs(grids, vec)
+        return (torch.tanh(v) if self.use_tanh else torch.sigmoid(v)), hx
+
+    def _pack(self, a_grid, a_pieces, a_b2b, a_combo, a_garbage, o_grid, o_pieces, o_b2b, o_combo, o_garbage, color):
+        n = a_grid.shape[0]
+        grids = torch.stack([a_grid.reshape(n, -1), o_grid.reshape(n, -1)]).to(torch.float32)
+        cols = [a_pieces.reshape(n, -1), a_b2b.reshape(n, 1), a_combo.reshape(n, 1), a_garbage.reshape(n, 1),
+                o_pieces.reshape(n, -1), o_b2b.reshape(n, 1), o_combo.reshape(n, 1), o_garbage.reshape(n, 1), color.reshape(n, 1)]
+        return grids, torch.cat([c.to(torch.float32) for c in cols], dim=1)
+
+    @torch.no_grad()
+    def forward(self, *features):
+        grids, vec = self._pack(*features)
+        v, logits = self.heads(grids, vec)
+        v = torch.tanh(v) if self.use_tanh else torch.sigmoid(v)
+        return v.reshape(-1, 1), logits
+
+
+class AuxBaseResNet(BaseResNet):
+    """BaseResNet + the 2-output auxiliary head (holes, height; architectures.py:308-353); forward returns
+    (value, policy logits, aux) like the reference, the search ignores aux (ai.py:1316)."""
+
+    has_aux = True
+
+    def __init__(self, model_config=None, use_tanh=False):
+        mc = model_config or AuxBaseResNetConfig()
+        super().__init__(mc, use_tanh)
+        head_in = mc.own_kernels * ROWS * COLS + PIECES_PER_PLAYER + SCALARS_PER_PLAYER + 1
+        self.aux_head = nn.ModuleDict({"0": nn.Linear(head_in, mc.aux_hidden), "1": nn.BatchNorm1d(mc.aux_hidden),
+                                       "3": nn.Linear(mc.aux_hidden, 2)})
+        self.eval()
+
+    @torch.no_grad()
+    def forward(self, *features):
+        grids, vec = self._pack(*features)
+        fd = self._folded or self.prepare()._folded
+        v, hx = self.head_inputs(grids, vec)
+        logits = F.linear(hx, self.policy_head.weight, self.policy_head.bias)
+        aux = torch.sigmoid(F.linear(torch.relu(F.linear(hx, *fd["a0"])), self.aux_head["3"].weight, self.aux_head["3"].bias))
+        v = torch.tanh(v) if self.use_tanh else torch.sigmoid(v)
+        return v.reshape(-1, 1), logits, aux
