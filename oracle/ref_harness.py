@@ -37,9 +37,28 @@ def import_reference(with_ai=False):
                   "absl.logging", "imageio", "imageio.v3", "skopt", "matplotlib", "matplotlib.pyplot",
                   "sklearn", "sklearn.model_selection"]
         sys.modules.setdefault("ujson", json)
+    import importlib
+    import importlib.machinery
+    import types
+
+    class _Stub(types.ModuleType):             # a module object (find_spec works on it) whose attributes are mocks
+        def __getattr__(self, key):
+            if key.startswith("__"):
+                raise AttributeError(key)
+            m = MagicMock()
+            setattr(self, key, m)
+            return m
+
     for name in stubs:
-        if name not in sys.modules:
-            sys.modules[name] = MagicMock()
+        if name in sys.modules:
+            continue
+        try:                                   # stub only what is really absent (sklearn, matplotlib exist here)
+            importlib.import_module(name)
+        except Exception:
+            mod = _Stub(name)
+            mod.__spec__ = importlib.machinery.ModuleSpec(name, None)
+            mod.__path__ = []
+            sys.modules[name] = mod
     if REFERENCE_DIR not in sys.path:
         sys.path.insert(0, REFERENCE_DIR)
     mods = {}

@@ -97,12 +97,19 @@ def test_graph_and_eager_ticks_agree():
     assert np.array_equal(out[0]["chosen"], out[1]["chosen"]) and np.array_equal(out[0]["visits"], out[1]["visits"])
 
 
-def test_self_play_loop_writes_sets(tmp_path, monkeypatch):
+def test_self_play_loop_generates_trains_and_gates(tmp_path, monkeypatch):
+    """the whole outer loop of the reference (ai.py:2117-2198) on the device: data set -> learner -> gating
+    match -> promotion, twice, with tiny settings"""
     monkeypatch.setenv("TRL_STORAGE", str(tmp_path / "Storage"))
-    cfg = _tiny_cfg(training_games=3)
+    cfg = _tiny_cfg(training_games=3, battle_games=4, sets_to_train_with=2, batch_size=16)
     cfg.training = False
     n = trl.self_play_loop(cfg, max_sets=2, seed=1)
-    assert n == 2 and trl.highest_data_number(cfg) == 1 and trl.highest_model_number(cfg) == 0
+    assert n == 2 and trl.highest_data_number(cfg) == 1 and trl.highest_model_number(cfg) >= 0
+    logs = tmp_path / "Storage" / "logs"
+    assert len(open(logs / "training_log.jsonl").read().splitlines()) == 2
+    gl = [__import__("json").loads(l) for l in open(logs / "gating_log.jsonl").read().splitlines()]
+    assert len(gl) == 2 and all(g["total_games"] == 4 and g["challenger_wins"] + g["best_wins"] <= 4 for g in gl)
+    assert trl.highest_model_number(cfg) == sum(1 for g in gl if g["accepted"])
 
 
 def test_fused_hip_tower_matches_torch_tower(golden_dir):

@@ -19,3 +19,5 @@ from . import compat  # noqa: F401,E402
 from .compat import Game, get_move_matrix, get_move_list, evaluate, MCTS, search_statistics  # noqa: F401,E402
 from . import gating  # noqa: F401,E402
 from .gating import battle_networks  # noqa: F401,E402
+from . import learner  # noqa: F401,E402
+from .learner import train_network_pytorch, load_data_and_train_model  # noqa: F401,E402

@@ -1,0 +1,160 @@
+"""Learner on ROCm: train_network_pytorch / load_data_and_train_model of the
+reference (ai.py:1139-1220, 1871-1921) for the PyTorch net families, on the training sets the rollout
+engine writes.  Plain PyTorch (autograd, AdamW); the nets' training-mode forwards apply the layers in
+the reference's order so that loss values and updated weights match the reference step for step.
+"""
+import json
+import os
+import random
+
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from . import nets, selfplay
+
+ROWS, COLS, POLICY_SIZE = 40, 10, 27 * 39 * 11
+
+
+def compute_aux_targets(own_grid_batch):
+    """architectures.py:285-305: [holes, aggregate height] / (ROWS * COLS) of the own board"""
+    g = own_grid_batch.squeeze(1)
+    filled = (g > 0.5).float()
+    above = (torch.cumsum(filled, dim=1) > 0).float()
+    holes = ((1.0 - filled) * above).sum(dim=(1, 2))
+    any_filled = filled.sum(dim=1) > 0
+    top = filled.argmax(dim=1)
+    heights = torch.where(any_filled, (ROWS - top).float(), torch.zeros_like(top, dtype=torch.float))
+    return torch.stack([holes / float(ROWS * COLS), heights.sum(dim=1) / float(ROWS * COLS)], dim=1)
+
+
+# ---- training-mode forwards (layer order of architectures.py:119-142, 230-271, 325-353) -------------------
+def _alphasame_train(net, a_grid, a_pieces, a_b2b, a_combo, a_garbage, o_grid, o_pieces, o_b2b, o_combo, o_garbage, color):
+    p = net.model_config.dropout
+
+    def grid(x):
+        x = net.conv1(x)
+        for b in net.res_blocks:
+            h = b.conv_block1["2"](torch.relu(b.conv_block1["0"](x)))
+            h = b.conv_block2["3"](torch.relu(F.dropout(b.conv_block2["0"](h), p, net.training)))
+            x = h + x
+        x = torch.relu(net.batchnorm1(x))
+        return torch.relu(net.batchnorm2(net.kernel1(x))).flatten(1)
+
+    a = grid(a_grid)
+    o = torch.relu(net.osidedense["1"](net.osidedense["0"](grid(o_grid))))
+    x = torch.cat([a, a_pieces.flatten(1), a_b2b.unsqueeze(1), a_combo.unsqueeze(1), a_garbage.unsqueeze(1),
+                   o, o_pieces.flatten(1), o_b2b.unsqueeze(1), o_combo.unsqueeze(1), o_garbage.unsqueeze(1), color.unsqueeze(1)], dim=1)
+    v = net.value_head["3"](torch.relu(net.value_head["1"](net.value_head["0"](x))))
+    v = F.dropout(v, p, net.training)
+    return (torch.tanh(v) if net.use_tanh else torch.sigmoid(v)), net.policy_head(x)
+
+
+def _baseresnet_train(net, a_grid, a_pieces, a_b2b, a_combo, a_garbage, o_grid, o_pieces, o_b2b, o_combo, o_garbage, color):
+    def grid(x):
+        x = torch.relu(net.stem["1"](net.stem["0"](x)))
+        for b in net.trunk:
+            out = torch.relu(b.bn1(b.conv1(x)))
+            x = torch.relu(b.bn2(b.conv2(out)) + x)
+        return x
+
+    a_feat, o_feat = grid(a_grid), grid(o_grid)
+    o_col = torch.relu(net.opp_collapse["1"](net.opp_collapse["0"](o_feat))).flatten(1)
+    opp = torch.relu(net.opp_encode["1"](net.opp_encode["0"](torch.cat(
+        [o_col, o_pieces.flatten(1), o_b2b.unsqueeze(1), o_combo.unsqueeze(1), o_garbage.unsqueeze(1)], dim=1))))
+    own = [a_pieces.flatten(1), a_b2b.unsqueeze(1), a_combo.unsqueeze(1), a_garbage.unsqueeze(1), color.unsqueeze(1)]
+    bias = net.bias_project(torch.cat([opp] + own, dim=1))
+    flat = torch.relu(net.own_collapse["1"](net.own_collapse["0"](a_feat + bias.view(-1, bias.size(1), 1, 1)))).flatten(1)
+    hx = torch.cat([flat] + own, dim=1)
+    v = net.value_head["3"](torch.relu(net.value_head["1"](net.value_head["0"](hx))))
+    v = torch.tanh(v) if net.use_tanh else torch.sigmoid(v)
+    out = (v, net.policy_head(hx))
+    if net.has_aux:
+        out += (torch.sigmoid(net.aux_head["3"](torch.relu(net.aux_head["1"](net.aux_head["0"](hx))))),)
+    return out
+
+
+def forward_train(net, *features):
+    """autograd-enabled forward with the reference's layer order (BN batch statistics / dropout follow net.training)"""
+    if isinstance(net, nets.AlphaSame):
+        return _alphasame_train(net, *features)
+    if isinstance(net, nets.BaseResNet):
+        return _baseresnet_train(net, *features)
+    raise TypeError("no training forward for %r" % type(net).__name__)
+
+
+# ---- ai.py:1139-1220 -------------------------------------------------------------------------------------------
+def train_network_pytorch(config, model, set, data_number=None, device=None):
+    device = device or next(model.parameters()).device
+    features = list(map(list, zip(*set)))
+    for i in range(len(features)):
+        features[i] = torch.tensor(features[i])
+        if features[i].dim() == 3 and features[i].shape[1] == ROWS and features[i].shape[2] == COLS:
+            features[i] = features[i].unsqueeze(dim=1).type(torch.float)
+    dataset = torch.utils.data.TensorDataset(*features)
+    loader = torch.utils.data.DataLoader(dataset, batch_size=config.batch_size, shuffle=config.shuffle)
+    loss_value, loss_policy, loss_aux = nn.MSELoss(), nn.CrossEntropyLoss(), nn.MSELoss()
+    optimizer = torch.optim.AdamW(model.parameters(), lr=config.learning_rate, weight_decay=config.weight_decay)
+    has_aux = isinstance(config.model_config, nets.AuxBaseResNetConfig)
+    aux_weight = config.model_config.aux_weight if has_aux else 0.0
+    model.train()
+    total = v_sum = p_sum = a_sum = 0.0
+    batches = 0
+    for _ in range(config.epochs):
+        for batch in loader:
+            batch = [t.to(device) for t in batch]
+            y_policy = batch.pop().reshape(-1, POLICY_SIZE)
+            y_value = batch.pop().type(torch.float)
+            out = forward_train(model, *batch)
+            pred_value, pred_policy = out[0].reshape(-1), out[1].reshape(-1, POLICY_SIZE)
+            l1, l2 = loss_value(pred_value, y_value), loss_policy(pred_policy, y_policy)
+            loss = l1 + l2
+            if has_aux:
+                l3 = loss_aux(out[2], compute_aux_targets(batch[0]))
+                loss = loss + aux_weight * l3
+                a_sum += l3.item()
+            loss.backward()
+            optimizer.step()
+            optimizer.zero_grad()
+            v_sum += l1.item(); p_sum += l2.item(); total += loss.item()
+            batches += 1
+    model.eval()
+    model._folded = None                      # the folded inference weights are stale now
+    nb = max(batches, 1)
+    entry = {"model_version": config.model_version,
+             "data_number": data_number if data_number is not None else selfplay.highest_data_number(config),
+             "loss": total / nb, "value_loss": v_sum / nb, "policy_loss": p_sum / nb, "backend": "pytorch"}
+    if has_aux:
+        entry["aux_loss"] = a_sum / nb
+    logs = selfplay.storage_root() / "logs"
+    logs.mkdir(parents=True, exist_ok=True)
+    with open(logs / "training_log.jsonl", "a") as f:
+        f.write(json.dumps(entry) + "\n")
+    return entry
+
+
+def get_data_filenames(config):
+    """ai.py:1943-1973: the newest `sets_to_train_with` set files"""
+    path, newest = config.data_dir, selfplay.highest_data_number(config)
+    names = [n for n in os.listdir(path) if n.split(".")[0].isdigit() and int(n.split(".")[0]) > newest - config.sets_to_train_with]
+    if config.shuffle:
+        random.shuffle(names)
+    return names
+
+
+def load_data_and_train_model(config, model, data=None):
+    """ai.py:1871-1921, 'merge' style: newer sets are sampled fully, older ones with decay_factor ** age"""
+    if config.data_loading_style != "merge":
+        raise NotImplementedError
+    if data is None:
+        data = []
+        names = sorted(get_data_filenames(config), key=lambda x: int(x.split(".")[0]), reverse=True)
+        for age, name in enumerate(names):
+            with open("%s/%s" % (config.data_dir, name)) as f:
+                s = json.load(f)
+            data.extend(random.sample(s, int(len(s) * config.decay_factor ** age)))
+    else:
+        data = [x for s in data for x in s]
+    if config.shuffle:
+        random.shuffle(data)
+    return train_network_pytorch(config, model, data)

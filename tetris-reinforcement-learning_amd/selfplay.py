@@ -349,22 +349,45 @@ def make_training_set(config, interference_network, num_games, save_game=False, 
 
 
 def self_play_loop(config, skip_first_set=False, max_sets=None, train_fn=None, gate_fn=None, seed=0):
-    """ai.py:2117-2198, data-generation side: repeatedly plays `training_games` games with the best
-    model on disk and writes one data set per loop.  The learner and the gating match are outside
-    the rollout path; `train_fn(config)` / `gate_fn(config)` are called where the
-    reference runs them, if given.  `max_sets` bounds the otherwise endless loop."""
+    """ai.py:2117-2198: generate a training set with the best model, train a challenger on the recent
+    sets, play the gating match, promote the challenger if it meets the threshold -- forever, or
+    `max_sets` times.  `train_fn(config, model)` / `gate_fn(challenger, config, best, config, threshold,
+    threshold_type, games) -> (wins, accepted)` replace the built-in learner / gating match."""
+    import torch
+    from datetime import datetime
+    from . import gating, learner
     if highest_model_number(config) == -1:
         instantiate_network(config, save_network=True)
-    sets = 0
-    while max_sets is None or sets < max_sets:
-        net = load_best_model(config)
-        tc = config.copy()
-        tc.training = True
-        if not (skip_first_set and sets == 0):
-            make_training_set(tc, net, config.training_games, save_game=True, save_stats=True, seed=seed + sets)
-        if train_fn is not None:
-            train_fn(config)
-        if gate_fn is not None:
-            gate_fn(config)
-        sets += 1
-    return sets
+    best = load_best_model(config)
+    training_config = config.copy()
+    training_config.training = True
+    logs = storage_root() / "logs"
+    logs.mkdir(parents=True, exist_ok=True)
+    it = 0
+    while max_sets is None or it < max_sets:
+        it += 1
+        challenger = load_best_model(config)
+        if not skip_first_set:
+            for i in range(config.training_loops):
+                make_training_set(training_config, challenger, config.training_games, save_game=True, save_stats=True,
+                                  seed=seed + 1000 * it + i)
+        else:
+            skip_first_set = False
+        dev = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
+        challenger = challenger.to(dev)
+        (train_fn or learner.load_data_and_train_model)(config, challenger)
+        next_ver = highest_model_number(config) + 1
+        win_loss, win = (gate_fn or gating.battle_networks)(challenger, config, best, config, config.gating_threshold,
+                                                            config.gating_threshold_type, config.battle_games)
+        entry = {"model_version": config.model_version, "challenger_number": next_ver, "challenger_wins": int(win_loss[0]),
+                 "best_wins": int(win_loss[1]), "total_games": config.battle_games,
+                 "win_rate": float(win_loss[0]) / config.battle_games, "accepted": bool(win)}
+        with open(logs / "gating_log.jsonl", "a") as f:
+            f.write(json.dumps(entry) + "\n")
+        if win:
+            torch.save(challenger.state_dict(), "%s/%d.pt" % (config.model_dir, next_ver))
+            with open(Path(config.model_dir) / "versions.jsonl", "a") as f:           # append_version_record, ai.py:224-234
+                f.write(json.dumps({"timestamp": datetime.utcnow().isoformat() + "Z", "model_number": next_ver,
+                                    "backend": config.model}) + "\n")
+            best = challenger
+    return it
