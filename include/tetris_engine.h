@@ -259,6 +259,17 @@ int  trl_mcts_create(trl_engine *h, const trl_mcts_config *cfg);
 /* tick part A.  dev_grids: float[2][n_games][40][10] (side to move first, then opponent --
  * simplify_grid, ai.py:1364-1377), dev_vec: float[n_games][TRL_VEC_FLOATS]; both device pointers. */
 int  trl_mcts_select(trl_engine *h, float *dev_grids, float *dev_vec);
+/* Tower-output reuse.  A move changes only the mover's board (game.py:66-118: lock, clear, own garbage), so
+ * the board of the side to move at a leaf is the board it had in the parent position and its tower output
+ * (process_grid, architectures.py:121-127) can be reused bit for bit instead of recomputed.
+ *   trl_mcts_select_need: as trl_mcts_select, and dev_need uint8[2][n_games] says which of the boards in
+ *                         dev_grids need the tower ([0] side to move: only at a search's root; [1] the player
+ *                         who just moved: every non-terminal leaf);
+ *   trl_mcts_zcache:      dev_z float[2][n_games][400] holds the tower outputs of the flagged boards; the call
+ *                         fills in the reused ones from the parent's cache entry and stores both outputs in the
+ *                         leaf's entry, so that afterwards dev_z is complete for the heads. */
+int  trl_mcts_select_need(trl_engine *h, float *dev_grids, float *dev_vec, uint8_t *dev_need);
+int  trl_mcts_zcache(trl_engine *h, float *dev_z);
 /* tick part B.  dev_values: float[n_games] (sigmoid value head), dev_policy: float[n_games][11583]
  * softmaxed policy, both as evaluate() returns them (ai.py:1222-1319). */
 int  trl_mcts_expand(trl_engine *h, const float *dev_values, const float *dev_policy);
@@ -289,6 +300,9 @@ int  trl_mcts_root_children(trl_engine *h, int32_t *counts, uint16_t *moves, int
  * tail s[16] t[16] wk[16] bk.  stream: hipStream_t (NULL = default stream).                        */
 int  trl_alphasame_trunk16(const float *dev_boards, int n_boards, const float *dev_packed, int n_blocks,
                            float *dev_out, void *stream);
+/* same, skipping the boards whose dev_need[board] is 0 (their dev_out rows are left untouched) */
+int  trl_alphasame_trunk16_need(const float *dev_boards, int n_boards, const float *dev_packed, int n_blocks,
+                                float *dev_out, const uint8_t *dev_need, void *stream);
 
 #ifdef __cplusplus
 }

@@ -201,3 +201,23 @@ def test_c5_configuration_runs():
     sp.tick(24)
     st = sp.stats()
     assert st["simulations"] == 24 * 32 and st["overflow"] == 0
+
+
+def test_tower_cache_is_bit_identical():
+    """reusing the unchanged board's tower output (trl_mcts_zcache) must not change a single visit count:
+    96 slots, 300 ticks (several searches incl. playout-cap short/long ones), with and without the cache"""
+    torch.manual_seed(0)
+    net = trl.AlphaSame(trl.AlphaSameConfig(blocks=3, filters=16))
+    cfg = trl.Config(visual=False, model="pytorch", model_config=trl.AlphaSameConfig(blocks=3, filters=16), MAX_ITER=24,
+                     training=True)
+    out = []
+    for cache in (True, False):
+        sp = trl.SelfPlay(cfg, net, 96, seed=13, tower_cache=cache)
+        assert sp.tower_cache == cache
+        sp.tick(300)
+        r = sp.drain()
+        out.append(r[np.lexsort((r["kind"], r["ply"], r["slot"], r["episode"]))])
+    a, b = out
+    assert len(a) == len(b) > 96
+    assert np.array_equal(a["chosen"], b["chosen"]) and np.array_equal(a["visits"], b["visits"])
+    assert np.array_equal(a["state"], b["state"])

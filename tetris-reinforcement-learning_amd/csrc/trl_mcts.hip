@@ -33,7 +33,7 @@ struct SlotCtl {
     int32_t iter, max_iter, fast;
     int32_t n_nodes, n_states;
     int32_t leaf, leaf_kind, leaf_nlegal, leaf_state;
-    int32_t overflow, pad_;
+    int32_t overflow, leaf_parent_state;      // state index of the leaf's parent (-1 at the root)
     double  terminal_value;
 };
 
@@ -54,6 +54,7 @@ struct DevMcts {
     uint16_t *leaf_moves;       // [n_games][TRL_MAX_LEGAL]
     trl_record *recs;
     unsigned int *rec_count;
+    float *zcache;              // [n_games][cap_states][2 players][400]: tower output per expanded position and board
     unsigned long long *counters;   // 0 simulations, 1 moves, 2 games, 3 dropped, 4 max nodes, 5 overflow, 6 ticks
 };
 
@@ -120,7 +121,7 @@ __device__ __forceinline__ void copy_state(trl_game_state *dst, const trl_game_s
 }
 
 // ---- tick part A --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *real, float *grids, float *vec) {
+__global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *real, float *grids, float *vec, uint8_t *need) {
     __shared__ SelectShared sh;
     const int tid = threadIdx.x, slot = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t nb = (size_t)slot * M.max_nodes;
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
         for (int i = tid; i < 2 * TRL_GRID_FLOATS; i += BLOCK)
             grids[((size_t)(i / TRL_GRID_FLOATS) * M.n_games + slot) * TRL_GRID_FLOATS + (i % TRL_GRID_FLOATS)] = 0.f;
         for (int i = tid; i < TRL_VEC_FLOATS; i += BLOCK) vec[(size_t)slot * TRL_VEC_FLOATS + i] = 0.f;
+        if (need && tid == 0) { need[slot] = 0; need[M.n_games + slot] = 0; }
         return;
     }
     if (sh.ctl.phase == 0) {
@@ -211,9 +213,10 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
     }
 
     // STEP (ai.py:398-403): node.game = parent.game.copy(); make_move(move, add_bag=False)
-    int sidx;
+    int sidx, pstate = -1;
     if (node != 0) {
         const int par = M.t.parent[nb + node];
+        pstate = M.t.state[nb + par];
         copy_state(&sh.b.g, pool + M.t.state[nb + par], tid);
         __syncthreads();
         if (tid == 0) {
@@ -275,7 +278,13 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
     if (tid == 0) {
         SlotCtl &c = sh.ctl;
         c.iter += 1;
-        c.leaf = node; c.leaf_kind = kind; c.leaf_nlegal = nlegal; c.leaf_state = sidx;
+        c.leaf = node; c.leaf_kind = kind; c.leaf_nlegal = nlegal; c.leaf_state = sidx; c.leaf_parent_state = pstate;
+        if (need) {
+            // which boards need the tower: a move changes only the mover's board (game.py:66-118), so the side to
+            // move at the leaf keeps the tower output its board had in the parent position (trl_mcts_zcache)
+            need[slot] = (kind != 2 && node == 0) ? 1 : 0;                    // grids[0]: side to move
+            need[M.n_games + slot] = (kind != 2) ? 1 : 0;                     // grids[1]: the player who just moved
+        }
         if (kind == 2) {
             int w = g.p[0].game_over ? 1 : (g.p[1].game_over ? 0 : -1);      // Game.winner, game.py:217-225
             c.terminal_value = (w == g.turn) ? 1.0 : (w == 1 - g.turn) ? 0.0 : 0.5;
@@ -559,6 +568,27 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
     if (tid == 0) { M.ctl[slot] = sh.ctl; if (slot == 0) atomicAdd(&M.counters[6], 1ull); }
 }
 
+// tower-output cache.  z: [2][n][400] as written by the tower for the boards flagged by k_select.  Afterwards
+// z[0] / z[1] hold the outputs for the side to move / the other player of every evaluated leaf, and the
+// leaf's cache entry holds both (indexed by absolute player).
+__global__ __launch_bounds__(128) void k_zcache(DevMcts M, float *z) {
+    const int slot = blockIdx.x, tid = threadIdx.x;
+    const SlotCtl c = M.ctl[slot];
+    if (c.phase != 1 || c.leaf_kind == 2) return;
+    const trl_game_state *pool = M.pool + (size_t)slot * M.cap_states;
+    const int q = pool[c.leaf_state].turn;                       // side to move at the leaf
+    float *zc = M.zcache + ((size_t)slot * M.cap_states) * 800;
+    float *mine = zc + (size_t)c.leaf_state * 800;
+    float *za = z + (size_t)slot * 400, *zo = z + ((size_t)M.n_games + slot) * 400;
+    for (int i = tid; i < 400; i += 128) {
+        float a = (c.leaf_parent_state < 0) ? za[i] : zc[(size_t)c.leaf_parent_state * 800 + q * 400 + i];
+        float o = zo[i];
+        za[i] = a;
+        mine[q * 400 + i] = a;
+        mine[(1 - q) * 400 + i] = o;
+    }
+}
+
 // gather of the current leaf states (tests / host-side evaluators)
 __global__ void k_leaf_gather(DevMcts M, trl_game_state *out, int32_t *info) {
     const int slot = blockIdx.x, tid = threadIdx.x;
@@ -617,6 +647,7 @@ static void free_dev(DevMcts &d) {
     hipFree(d.t.parent); hipFree(d.t.first); hipFree(d.t.visit); hipFree(d.t.state); hipFree(d.t.nchild); hipFree(d.t.move);
     hipFree(d.t.wsum); hipFree(d.t.q); hipFree(d.t.prior); hipFree(d.t.pf32); hipFree(d.t.turn);
     hipFree(d.ctl); hipFree(d.pool); hipFree(d.leaf_moves); hipFree(d.recs); hipFree(d.rec_count); hipFree(d.counters);
+    hipFree(d.zcache);
 }
 
 void trl_mcts_free_internal(trl_engine *h) {
@@ -658,6 +689,7 @@ int trl_mcts_create(trl_engine *h, const trl_mcts_config *cfg) {
     HIPCHK(hipMalloc(&d.ctl, n * sizeof(SlotCtl)));
     HIPCHK(hipMalloc(&d.pool, n * d.cap_states * sizeof(trl_game_state)));
     HIPCHK(hipMalloc(&d.leaf_moves, n * TRL_MAX_LEGAL * 2));
+    HIPCHK(hipMalloc(&d.zcache, n * d.cap_states * 800 * sizeof(float)));
     HIPCHK(hipMalloc(&d.recs, (size_t)d.rec_cap * sizeof(trl_record)));
     HIPCHK(hipMalloc(&d.rec_count, 4));
     HIPCHK(hipMalloc(&d.counters, 8 * 8));
@@ -674,9 +706,21 @@ int trl_mcts_create(trl_engine *h, const trl_mcts_config *cfg) {
 }
 
 int trl_mcts_select(trl_engine *h, float *dev_grids, float *dev_vec) {
+    return trl_mcts_select_need(h, dev_grids, dev_vec, nullptr);
+}
+
+int trl_mcts_select_need(trl_engine *h, float *dev_grids, float *dev_vec, uint8_t *dev_need) {
     if (!h || !h->mcts || !dev_grids || !dev_vec) return fail(TRL_E_INVALID, "trl_mcts_select: %s", "null argument / no search attached");
     HIPCHK(hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(k_select, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_grids, dev_vec);
+    hipLaunchKernelGGL(k_select, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_grids, dev_vec, dev_need);
+    HIPCHK(hipGetLastError());
+    return TRL_OK;
+}
+
+int trl_mcts_zcache(trl_engine *h, float *dev_z) {
+    if (!h || !h->mcts || !dev_z) return fail(TRL_E_INVALID, "trl_mcts_zcache: %s", "null argument / no search attached");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    hipLaunchKernelGGL(k_zcache, dim3(h->cfg.n_games), dim3(128), 0, h->stream, h->mcts->d, dev_z);
     HIPCHK(hipGetLastError());
     return TRL_OK;
 }

@@ -73,7 +73,9 @@ __device__ __forceinline__ void conv3x3(const float *buf, const float *wp, float
 }
 
 __global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__restrict__ boards, const float *__restrict__ wts,
-                                                              int n_blocks, float *__restrict__ out) {
+                                                              int n_blocks, float *__restrict__ out,
+                                                              const uint8_t *__restrict__ need) {
+    if (need && !need[blockIdx.x]) return;      // board whose tower output is already cached (trl_mcts_zcache)
     __shared__ __attribute__((aligned(16))) float lds[BUF_FLOATS + BW * BH];
     float *bufA = lds, *brd = lds + BUF_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -176,10 +178,15 @@ extern "C" {
 // nets.AlphaSame.prepare() builds; out: device float[n_boards][400]; stream: hipStream_t.
 int trl_alphasame_trunk16(const float *dev_boards, int n_boards, const float *dev_packed, int n_blocks,
                           float *dev_out, void *stream) {
+    return trl_alphasame_trunk16_need(dev_boards, n_boards, dev_packed, n_blocks, dev_out, nullptr, stream);
+}
+
+int trl_alphasame_trunk16_need(const float *dev_boards, int n_boards, const float *dev_packed, int n_blocks,
+                               float *dev_out, const uint8_t *dev_need, void *stream) {
     if (!dev_boards || !dev_packed || !dev_out || n_boards <= 0 || n_blocks < 0)
         return fail(TRL_E_INVALID, "trl_alphasame_trunk16: %s", "bad argument");
     hipLaunchKernelGGL(k_trunk16, dim3(n_boards), dim3(TRUNK_THREADS), 0, (hipStream_t)stream, dev_boards, dev_packed,
-                       n_blocks, dev_out);
+                       n_blocks, dev_out, dev_need);
     HIPCHK(hipGetLastError());
     return TRL_OK;
 }

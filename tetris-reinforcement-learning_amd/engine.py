@@ -22,7 +22,8 @@ ABI_SYMBOLS = [
     "trl_env_legal_moves", "trl_env_legal_dev", "trl_env_step", "trl_env_step_dev",
     "trl_env_rollout_random", "trl_last_kernel_ms",
     "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_expand_head", "trl_mcts_drain_records", "trl_mcts_get_stats",
-    "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16",
+    "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16", "trl_alphasame_trunk16_need",
+    "trl_mcts_select_need", "trl_mcts_zcache",
 ]
 
 GRID_FLOATS = 400
@@ -118,6 +119,9 @@ def load_library(path=None):
     L.trl_mcts_get_stats.argtypes = [C.c_void_p, C.POINTER(TrlMctsStats)]
     L.trl_mcts_leaf_states.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.trl_mcts_root_children.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+    L.trl_mcts_select_need.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.trl_mcts_zcache.argtypes = [C.c_void_p, C.c_void_p]
+    L.trl_alphasame_trunk16_need.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.trl_alphasame_trunk16.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     _lib = L
     return L
@@ -224,6 +228,12 @@ class Engine:
 
     def mcts_select(self, grids_ptr, vec_ptr):
         _check(self._L, self._L.trl_mcts_select(self._h, grids_ptr, vec_ptr), "trl_mcts_select")
+
+    def mcts_select_need(self, grids_ptr, vec_ptr, need_ptr):
+        _check(self._L, self._L.trl_mcts_select_need(self._h, grids_ptr, vec_ptr, need_ptr), "trl_mcts_select_need")
+
+    def mcts_zcache(self, z_ptr):
+        _check(self._L, self._L.trl_mcts_zcache(self._h, z_ptr), "trl_mcts_zcache")
 
     def mcts_expand(self, values_ptr, policy_ptr):
         _check(self._L, self._L.trl_mcts_expand(self._h, values_ptr, policy_ptr), "trl_mcts_expand")

@@ -144,25 +144,44 @@ class AlphaSame(nn.Module):
         wk, bk = fd["k1"]
         return torch.relu(F.conv2d(torch.relu(x * s + t), wk, bk)).flatten(1)
 
-    def _trunk_hip(self, boards, packed):
-        """fused HIP tower (csrc/trl_net.hip) on the current stream; raises if the library is missing"""
+    def _trunk_hip(self, boards, packed, need=None):
+        """fused HIP tower (csrc/trl_net.hip) on the current stream; raises if the library is missing.
+        need: optional uint8 [m] -- boards with 0 are skipped (their output rows stay zero)"""
         from . import engine as _eng
         L = _eng.load_library()
         m = boards.shape[0]
         x = boards.reshape(m, ROWS * COLS).contiguous()
-        out = torch.empty((m, ROWS * COLS), dtype=torch.float32, device=boards.device)
-        rc = L.trl_alphasame_trunk16(x.data_ptr(), m, packed.data_ptr(), len(self.res_blocks), out.data_ptr(),
-                                     torch.cuda.current_stream(boards.device).cuda_stream)
+        if need is None:
+            out = torch.empty((m, ROWS * COLS), dtype=torch.float32, device=boards.device)
+        else:
+            out = torch.zeros((m, ROWS * COLS), dtype=torch.float32, device=boards.device)
+        rc = L.trl_alphasame_trunk16_need(x.data_ptr(), m, packed.data_ptr(), len(self.res_blocks), out.data_ptr(),
+                                          None if need is None else need.data_ptr(),
+                                          torch.cuda.current_stream(boards.device).cuda_stream)
         if rc != 0:
             raise _eng.EngineError("trl_alphasame_trunk16 failed: %s" % L.trl_last_error().decode())
         return out
 
+    @property
+    def supports_tower_cache(self):
+        """True when the tower runs as the fused HIP kernel, which can skip boards (trl_mcts_zcache flow)"""
+        fd = self._folded or self.prepare()._folded
+        return fd["packed16"] is not None and self.use_hip_trunk
+
     @torch.no_grad()
-    def head_inputs(self, grids, vec):
-        """-> (value [n] before the output activation, x [n, 521] = input of the policy head)"""
+    def tower_need(self, grids, need):
+        """tower outputs [2n, 400] of the boards flagged in need (uint8 [2n]); the others are zero"""
+        fd = self._folded or self.prepare()._folded
+        return self._trunk_hip(grids.reshape(-1, 1, ROWS, COLS), fd["packed16"], need)
+
+    @torch.no_grad()
+    def head_inputs(self, grids, vec, z=None):
+        """-> (value [n] before the output activation, x [n, 521] = input of the policy head);
+        z: precomputed tower outputs [2n, 400] (side to move first), else the tower runs on grids"""
         fd = self._folded or self.prepare()._folded
         n = vec.shape[0]
-        z = self.trunk(grids.reshape(2 * n, 1, ROWS, COLS))
+        if z is None:
+            z = self.trunk(grids.reshape(2 * n, 1, ROWS, COLS))
         wo, bo = fd["oside"]
         o = torch.relu(F.linear(z[n:], wo, bo))
         # concat order of the reference (architectures.py:132-140)
@@ -178,9 +197,9 @@ class AlphaSame(nn.Module):
         return v, F.linear(x, self.policy_head.weight, self.policy_head.bias)
 
     @torch.no_grad()
-    def evaluate_head_inputs(self, grids, vec):
+    def evaluate_head_inputs(self, grids, vec, z=None):
         """(value [n], x [n, 521]) for trl_mcts_expand_head, which forms only the legal logits itself"""
-        v, x = self.head_inputs(grids, vec)
+        v, x = self.head_inputs(grids, vec, z)
         return (torch.tanh(v) if self.use_tanh else torch.sigmoid(v)), x
 
     @torch.no_grad()

@@ -112,12 +112,13 @@ class SelfPlay:
     """n_slots concurrent self-play games: Engine + net + HIP-graph tick."""
 
     def __init__(self, config, network, n_slots, seed=0, device=0, streams=None, auto_reset=True, use_graph=True,
-                 max_nodes=0, record_capacity=0, policy_head="legal"):
+                 max_nodes=0, record_capacity=0, policy_head="legal", tower_cache=True):
         """policy_head: "legal" = only the legal moves' logits are formed, inside the expand kernel
         (trl_mcts_expand_head); "full" = the reference's data flow, softmax over all 11 583 logits."""
         if policy_head not in ("legal", "full"):
             raise ValueError("policy_head must be 'legal' or 'full'")
         self.policy_head = policy_head
+        self.tower_cache = bool(tower_cache)     # reuse the unchanged board's tower output (trl_mcts_zcache); exact
         import torch
         self.torch = torch
         self.config = config
@@ -133,6 +134,8 @@ class SelfPlay:
         with torch.cuda.stream(self.stream):
             self.grids = torch.zeros((2, self.n, _eng.GRID_FLOATS), dtype=torch.float32, device=self.device)
             self.vec = torch.zeros((self.n, _eng.VEC_FLOATS), dtype=torch.float32, device=self.device)
+            self.need = torch.ones(2 * self.n, dtype=torch.uint8, device=self.device)
+        self.tower_cache = self.tower_cache and policy_head == "legal" and getattr(self.net, "supports_tower_cache", False)
         self.stream.synchronize()
         self.graph = None
         self.ticks = 0
@@ -141,8 +144,16 @@ class SelfPlay:
 
     def _tick_body(self):
         e = self.engine
+        # v / p / x / z live in the stream-ordered allocator (a fixed address inside a captured graph)
+        if self.tower_cache:
+            e.mcts_select_need(self.grids.data_ptr(), self.vec.data_ptr(), self.need.data_ptr())
+            z = self.net.tower_need(self.grids, self.need)
+            e.mcts_zcache(z.data_ptr())
+            v, x = self.net.evaluate_head_inputs(self.grids, self.vec, z)
+            ph = self.net.policy_head
+            e.mcts_expand_head(v.data_ptr(), x.data_ptr(), x.shape[1], ph.weight.data_ptr(), ph.bias.data_ptr())
+            return
         e.mcts_select(self.grids.data_ptr(), self.vec.data_ptr())
-        # v / p / x live in the stream-ordered allocator (a fixed address inside a captured graph)
         if self.policy_head == "full":
             v, p = self.net.evaluate_packed(self.grids, self.vec)
             e.mcts_expand(v.data_ptr(), p.data_ptr())
