@@ -281,6 +281,20 @@ int  trl_mcts_expand(trl_engine *h, const float *dev_values, const float *dev_po
  * moves (ai.py:436-443), so the priors are the same up to float32 rounding (~1e-7 relative). */
 int  trl_mcts_expand_head(trl_engine *h, const float *dev_values, const float *dev_feats, int feat_dim,
                           const float *dev_head_weight, const float *dev_head_bias);
+/* tick part B for AlphaSame with every head inside the kernel: dev_z float[2][n_games][400] = tower outputs of
+ * the boards trl_mcts_select_need flagged (the call completes them from the tower-output cache exactly as
+ * trl_mcts_zcache does), dev_vec = the float[n_games][105] of trl_mcts_select.  The kernel forms the 521-vector
+ * of architectures.py:132-140, the opponent-side dense layer, the value head and the legal moves' logits.
+ * Weights: eval-mode BatchNorm1d folded into the preceding Linear (nets.AlphaSame.prepare()). */
+typedef struct trl_alphasame_heads {
+    const float *oside_w, *oside_b;       /* [16][400], [16]      osidedense.0 + .1 folded            */
+    const float *value0_w, *value0_b;     /* [16][521], [16]      value_head.0 + .1 folded            */
+    const float *value3_w;                /* [16]                 value_head.3.weight                  */
+    const float *policy_w, *policy_b;     /* [11583][521], [11583] policy_head                         */
+    float value3_b;                       /* value_head.3.bias                                          */
+    int32_t use_tanh;                     /* output activation of the value head: 0 sigmoid, 1 tanh     */
+} trl_alphasame_heads;
+int  trl_mcts_expand_alphasame(trl_engine *h, const float *dev_z, const float *dev_vec, const trl_alphasame_heads *w);
 /* copy out and clear the pending records (host buffer of `cap` records); returns the count in *n_out */
 int  trl_mcts_drain_records(trl_engine *h, trl_record *host_out, int cap, int *n_out);
 int  trl_mcts_get_stats(trl_engine *h, trl_mcts_stats *host_out);

@@ -221,3 +221,31 @@ def test_tower_cache_is_bit_identical():
     assert len(a) == len(b) > 96
     assert np.array_equal(a["chosen"], b["chosen"]) and np.array_equal(a["visits"], b["visits"])
     assert np.array_equal(a["state"], b["state"])
+
+
+def test_device_heads_match_torch_heads():
+    """trl_mcts_expand_alphasame (dense heads + cache assembly inside the expand kernel) against the PyTorch
+    heads: same root children, priors and Q to float32 rounding, nearly all first moves equal"""
+    torch.manual_seed(0)
+    net = trl.AlphaSame(trl.AlphaSameConfig(blocks=10, filters=16))
+    cfg = trl.Config(visual=False, model="pytorch", model_config=trl.AlphaSameConfig(blocks=10, filters=16), MAX_ITER=32,
+                     training=False)
+    res = {}
+    for dh in (False, True):
+        sp = trl.SelfPlay(cfg, net, 64, seed=9, auto_reset=False, device_heads=dh, use_graph=False)
+        assert (sp.heads is not None) == dh and sp.tower_cache
+        sp.tick(2)
+        sp.synchronize()
+        c, m, v, q, p = sp.engine.mcts_root_children()
+        sp.tick(30)
+        rec = sp.drain()
+        res[dh] = (c, m, p, q, v, rec[np.argsort(rec["slot"], kind="stable")])
+    c0, m0, p0, q0, v0, r0 = res[False]
+    c1, m1, p1, q1, v1, r1 = res[True]
+    assert np.array_equal(c0, c1)
+    for g in range(64):
+        n = c0[g]
+        assert np.array_equal(m0[g, :n], m1[g, :n]) and np.array_equal(v0[g, :n], v1[g, :n])
+        assert np.allclose(p0[g, :n], p1[g, :n], rtol=2e-5, atol=1e-9)
+        assert np.allclose(q0[g, :n], q1[g, :n], rtol=0, atol=2e-6)
+    assert int((r0["chosen"] == r1["chosen"]).sum()) >= 60

@@ -109,6 +109,8 @@ struct ExpandShared {
     float  pf[TRL_MAX_LEGAL];
     double pd[TRL_MAX_LEGAL];
     float  xs[HEAD_MAX_FEATS];
+    float  zo[400];
+    float  hv[20];
     float  red_f[2];
     double dsum;
     int    flag, chosen, rec_idx, end_idx;
@@ -301,9 +303,23 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
 //               head; only the logits of the legal moves are formed (one wavefront per move, the
 //               weight row read coalesced), p_i = exp(l_i - max_legal).  The softmax denominator
 //               cancels in every use the search makes of the priors (ai.py:428-443).
-template <bool HEAD>
+// MODE 0: softmaxed policy given; MODE 1: policy-head input given (HEAD path above);
+// MODE 2: AlphaSame heads entirely in this kernel -- `policy` is the tower output z[2][n][400] of the boards
+//         k_select flagged, `values` is the packed feature vector vec[n][105]; the kernel completes z from the
+//         tower-output cache (see k_zcache), forms the 521-vector (architectures.py:132-140), the opponent-side
+//         dense layer, the value head and the legal moves' logits.
+struct HeadsDev {
+    const float *oside_w, *oside_b;      // [16][400], [16]   (Linear + BatchNorm1d folded)
+    const float *v0_w, *v0_b;            // [16][521], [16]   (Linear + BatchNorm1d folded)
+    const float *v3_w;                   // [16]
+    float v3_b;
+    int use_tanh;
+};
+
+template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *real, const float *values, const float *policy,
-                                                  const float *head_w, const float *head_b, int feat_dim) {
+                                                  const float *head_w, const float *head_b, int feat_dim, HeadsDev H) {
+    constexpr bool HEAD = (MODE >= 1);
     __shared__ ExpandShared sh;
     const int tid = threadIdx.x, slot = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t nb = (size_t)slot * M.max_nodes;
@@ -314,7 +330,44 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
     if (sh.ctl.phase != 1) return;
     const int leaf = sh.ctl.leaf, kind = sh.ctl.leaf_kind;
     const double value_min = 0.0;
-    double value = (kind == 2) ? sh.ctl.terminal_value : (double)values[slot];
+    if (MODE == 2 && kind != 2) {
+        // complete z from the cache, store the leaf's entry, build x = [z_own, own extras, oside(z_opp), opp extras, colour]
+        const float *z = policy, *vecp = values + (size_t)slot * TRL_VEC_FLOATS;
+        const int q = pool[sh.ctl.leaf_state].turn, ps = sh.ctl.leaf_parent_state;
+        float *zc = M.zcache + ((size_t)slot * M.cap_states) * 800;
+        float *mine = zc + (size_t)sh.ctl.leaf_state * 800;
+        for (int i = tid; i < 400; i += BLOCK) {
+            float a = (ps < 0) ? z[(size_t)slot * 400 + i] : zc[(size_t)ps * 800 + q * 400 + i];
+            float o = z[((size_t)M.n_games + slot) * 400 + i];
+            sh.xs[i] = a; sh.zo[i] = o;
+            mine[q * 400 + i] = a; mine[(1 - q) * 400 + i] = o;
+        }
+        for (int i = tid; i < TRL_VEC_FLOATS; i += BLOCK) sh.xs[i < 52 ? 400 + i : 416 + i] = vecp[i];
+        __syncthreads();
+        for (int j = wave * 8; j < wave * 8 + 8; j++) {                       // opponent-side dense 400 -> 16, ReLU
+            float a = 0.f;
+            for (int i = lane; i < 400; i += 64) a = fmaf(H.oside_w[j * 400 + i], sh.zo[i], a);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+            if (lane == 0) sh.xs[452 + j] = fmaxf(a + H.oside_b[j], 0.f);
+        }
+        __syncthreads();
+        for (int j = wave * 8; j < wave * 8 + 8; j++) {                       // value head 521 -> 16, ReLU
+            float a = 0.f;
+            for (int i = lane; i < 521; i += 64) a = fmaf(H.v0_w[j * 521 + i], sh.xs[i], a);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+            if (lane == 0) sh.hv[j] = fmaxf(a + H.v0_b[j], 0.f);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float v = H.v3_b;
+            for (int j = 0; j < 16; j++) v = fmaf(sh.hv[j], H.v3_w[j], v);
+            sh.hv[16] = H.use_tanh ? tanhf(v) : 1.0f / (1.0f + expf(-v));
+        }
+        __syncthreads();
+    }
+    double value = (kind == 2) ? sh.ctl.terminal_value : (MODE == 2 ? (double)sh.hv[16] : (double)values[slot]);
 
     // EXPAND (ai.py:411-458)
     if (kind == 0) {
@@ -324,9 +377,11 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
         const uint16_t *lm = M.leaf_moves + (size_t)slot * TRL_MAX_LEGAL;
         float mymax = 0.f;
         if (HEAD) {
-            const float *xf = policy + (size_t)slot * feat_dim;
-            for (int i = tid; i < feat_dim; i += BLOCK) sh.xs[i] = xf[i];      // the leaf's feature vector, staged once
-            __syncthreads();
+            if (MODE == 1) {
+                const float *xf = policy + (size_t)slot * feat_dim;
+                for (int i = tid; i < feat_dim; i += BLOCK) sh.xs[i] = xf[i];  // the leaf's feature vector, staged once
+                __syncthreads();
+            }
             float lmax = -INFINITY;
             for (int k = wave; k < n; k += BLOCK / 64) {
                 int m = lm[k];
@@ -728,8 +783,8 @@ int trl_mcts_zcache(trl_engine *h, float *dev_z) {
 int trl_mcts_expand(trl_engine *h, const float *dev_values, const float *dev_policy) {
     if (!h || !h->mcts || !dev_values || !dev_policy) return fail(TRL_E_INVALID, "trl_mcts_expand: %s", "null argument / no search attached");
     HIPCHK(hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(k_expand<false>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_values,
-                       dev_policy, (const float *)nullptr, (const float *)nullptr, 0);
+    hipLaunchKernelGGL(k_expand<0>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_values,
+                       dev_policy, (const float *)nullptr, (const float *)nullptr, 0, HeadsDev{});
     HIPCHK(hipGetLastError());
     h->mcts->ticks++;
     return TRL_OK;
@@ -740,8 +795,21 @@ int trl_mcts_expand_head(trl_engine *h, const float *dev_values, const float *de
     if (!h || !h->mcts || !dev_values || !dev_feats || !dev_head_weight || !dev_head_bias || feat_dim <= 0 || feat_dim > HEAD_MAX_FEATS)
         return fail(TRL_E_INVALID, "trl_mcts_expand_head: %s", "bad argument / no search attached");
     HIPCHK(hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(k_expand<true>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_values,
-                       dev_feats, dev_head_weight, dev_head_bias, feat_dim);
+    hipLaunchKernelGGL(k_expand<1>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_values,
+                       dev_feats, dev_head_weight, dev_head_bias, feat_dim, HeadsDev{});
+    HIPCHK(hipGetLastError());
+    h->mcts->ticks++;
+    return TRL_OK;
+}
+
+int trl_mcts_expand_alphasame(trl_engine *h, const float *dev_z, const float *dev_vec, const trl_alphasame_heads *w) {
+    if (!h || !h->mcts || !dev_z || !dev_vec || !w || !w->oside_w || !w->oside_b || !w->value0_w || !w->value0_b ||
+        !w->value3_w || !w->policy_w || !w->policy_b)
+        return fail(TRL_E_INVALID, "trl_mcts_expand_alphasame: %s", "null argument / no search attached");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HeadsDev H{w->oside_w, w->oside_b, w->value0_w, w->value0_b, w->value3_w, w->value3_b, w->use_tanh};
+    hipLaunchKernelGGL(k_expand<2>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_vec,
+                       dev_z, w->policy_w, w->policy_b, 521, H);
     HIPCHK(hipGetLastError());
     h->mcts->ticks++;
     return TRL_OK;

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "trl_env_rollout_random", "trl_last_kernel_ms",
     "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_expand_head", "trl_mcts_drain_records", "trl_mcts_get_stats",
     "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16", "trl_alphasame_trunk16_need",
-    "trl_mcts_select_need", "trl_mcts_zcache",
+    "trl_mcts_select_need", "trl_mcts_zcache", "trl_mcts_expand_alphasame",
 ]
 
 GRID_FLOATS = 400
@@ -61,6 +61,12 @@ RECORD_DTYPE = np.dtype([("slot", "<u4"), ("episode", "<u4"), ("ply", "<u4"), ("
                          ("state", "u1", (320,)), ("moves", "<u2", (512,)), ("visits", "<u2", (512,))])
 assert RECORD_DTYPE.itemsize == 2392
 REC_MOVE, REC_GAME_END = 0, 1
+
+
+class TrlAlphaSameHeads(C.Structure):
+    _fields_ = [("oside_w", C.c_void_p), ("oside_b", C.c_void_p), ("value0_w", C.c_void_p), ("value0_b", C.c_void_p),
+                ("value3_w", C.c_void_p), ("policy_w", C.c_void_p), ("policy_b", C.c_void_p), ("value3_b", C.c_float),
+                ("use_tanh", C.c_int32)]
 
 
 class TrlMctsStats(C.Structure):
@@ -121,6 +127,7 @@ def load_library(path=None):
     L.trl_mcts_root_children.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     L.trl_mcts_select_need.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.trl_mcts_zcache.argtypes = [C.c_void_p, C.c_void_p]
+    L.trl_mcts_expand_alphasame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(TrlAlphaSameHeads)]
     L.trl_alphasame_trunk16_need.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.trl_alphasame_trunk16.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     _lib = L
@@ -234,6 +241,9 @@ class Engine:
 
     def mcts_zcache(self, z_ptr):
         _check(self._L, self._L.trl_mcts_zcache(self._h, z_ptr), "trl_mcts_zcache")
+
+    def mcts_expand_alphasame(self, z_ptr, vec_ptr, heads):
+        _check(self._L, self._L.trl_mcts_expand_alphasame(self._h, z_ptr, vec_ptr, C.byref(heads)), "trl_mcts_expand_alphasame")
 
     def mcts_expand(self, values_ptr, policy_ptr):
         _check(self._L, self._L.trl_mcts_expand(self._h, values_ptr, policy_ptr), "trl_mcts_expand")

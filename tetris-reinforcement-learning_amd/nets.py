@@ -168,6 +168,20 @@ class AlphaSame(nn.Module):
         fd = self._folded or self.prepare()._folded
         return fd["packed16"] is not None and self.use_hip_trunk
 
+    def device_heads(self):
+        """trl_alphasame_heads for trl_mcts_expand_alphasame (pointers into the folded tensors of prepare())"""
+        from . import engine as _eng
+        fd = self._folded or self.prepare()._folded
+        mc = self.model_config
+        if mc.o_side_neurons != 16 or mc.value_head_neurons != 16:
+            return None
+        (wo, bo), (wv, bv) = fd["oside"], fd["v0"]
+        w3, b3 = self.value_head["3"].weight.reshape(-1).contiguous(), float(self.value_head["3"].bias.item())
+        fd["_keep"] = (w3,)
+        ph = self.policy_head
+        return _eng.TrlAlphaSameHeads(wo.data_ptr(), bo.data_ptr(), wv.data_ptr(), bv.data_ptr(), w3.data_ptr(),
+                                      ph.weight.data_ptr(), ph.bias.data_ptr(), b3, int(bool(self.use_tanh)))
+
     @torch.no_grad()
     def tower_need(self, grids, need):
         """tower outputs [2n, 400] of the boards flagged in need (uint8 [2n]); the others are zero"""

@@ -112,7 +112,7 @@ class SelfPlay:
     """n_slots concurrent self-play games: Engine + net + HIP-graph tick."""
 
     def __init__(self, config, network, n_slots, seed=0, device=0, streams=None, auto_reset=True, use_graph=True,
-                 max_nodes=0, record_capacity=0, policy_head="legal", tower_cache=True):
+                 max_nodes=0, record_capacity=0, policy_head="legal", tower_cache=True, device_heads=True):
         """policy_head: "legal" = only the legal moves' logits are formed, inside the expand kernel
         (trl_mcts_expand_head); "full" = the reference's data flow, softmax over all 11 583 logits."""
         if policy_head not in ("legal", "full"):
@@ -136,6 +136,8 @@ class SelfPlay:
             self.vec = torch.zeros((self.n, _eng.VEC_FLOATS), dtype=torch.float32, device=self.device)
             self.need = torch.ones(2 * self.n, dtype=torch.uint8, device=self.device)
         self.tower_cache = self.tower_cache and policy_head == "legal" and getattr(self.net, "supports_tower_cache", False)
+        # every head of AlphaSame inside the expand kernel (trl_mcts_expand_alphasame): the tick is three HIP kernels
+        self.heads = self.net.device_heads() if (self.tower_cache and device_heads and hasattr(self.net, "device_heads")) else None
         self.stream.synchronize()
         self.graph = None
         self.ticks = 0
@@ -148,6 +150,9 @@ class SelfPlay:
         if self.tower_cache:
             e.mcts_select_need(self.grids.data_ptr(), self.vec.data_ptr(), self.need.data_ptr())
             z = self.net.tower_need(self.grids, self.need)
+            if self.heads is not None:
+                e.mcts_expand_alphasame(z.data_ptr(), self.vec.data_ptr(), self.heads)
+                return
             e.mcts_zcache(z.data_ptr())
             v, x = self.net.evaluate_head_inputs(self.grids, self.vec, z)
             ph = self.net.policy_head
