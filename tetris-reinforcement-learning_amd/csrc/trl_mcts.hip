@@ -344,20 +344,48 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
         }
         for (int i = tid; i < TRL_VEC_FLOATS; i += BLOCK) sh.xs[i < 52 ? 400 + i : 416 + i] = vecp[i];
         __syncthreads();
-        for (int j = wave * 8; j < wave * 8 + 8; j++) {                       // opponent-side dense 400 -> 16, ReLU
-            float a = 0.f;
-            for (int i = lane; i < 400; i += 64) a = fmaf(H.oside_w[j * 400 + i], sh.zo[i], a);
+        {                                                                     // opponent-side dense 400 -> 16, ReLU
+            float zr[7];                                                      // all weight loads of a wave's 8 rows are issued
+#pragma unroll                                                                 // before the first use: one L2 round trip
+            for (int t = 0; t < 7; t++) zr[t] = (lane + 64 * t < 400) ? sh.zo[lane + 64 * t] : 0.f;
+            float acc[8];
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
-            if (lane == 0) sh.xs[452 + j] = fmaxf(a + H.oside_b[j], 0.f);
+            for (int jj = 0; jj < 8; jj++) {
+                const float *row = H.oside_w + (wave * 8 + jj) * 400;
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < 7; t++) a = fmaf((lane + 64 * t < 400) ? row[lane + 64 * t] : 0.f, zr[t], a);
+                acc[jj] = a;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                float a = acc[jj];
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+                if (lane == 0) sh.xs[452 + wave * 8 + jj] = fmaxf(a + H.oside_b[wave * 8 + jj], 0.f);
+            }
         }
         __syncthreads();
-        for (int j = wave * 8; j < wave * 8 + 8; j++) {                       // value head 521 -> 16, ReLU
-            float a = 0.f;
-            for (int i = lane; i < 521; i += 64) a = fmaf(H.v0_w[j * 521 + i], sh.xs[i], a);
+        {                                                                     // value head 521 -> 16, ReLU
+            float xr[9];
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
-            if (lane == 0) sh.hv[j] = fmaxf(a + H.v0_b[j], 0.f);
+            for (int t = 0; t < 9; t++) xr[t] = (lane + 64 * t < 521) ? sh.xs[lane + 64 * t] : 0.f;
+            float acc[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                const float *row = H.v0_w + (wave * 8 + jj) * 521;
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; t++) a = fmaf((lane + 64 * t < 521) ? row[lane + 64 * t] : 0.f, xr[t], a);
+                acc[jj] = a;
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                float a = acc[jj];
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+                if (lane == 0) sh.hv[wave * 8 + jj] = fmaxf(a + H.v0_b[wave * 8 + jj], 0.f);
+            }
         }
         __syncthreads();
         if (tid == 0) {
@@ -383,17 +411,49 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
                 __syncthreads();
             }
             float lmax = -INFINITY;
-            for (int k = wave; k < n; k += BLOCK / 64) {
-                int m = lm[k];
-                int idx = (TRL_MOVE_PLANE(m) * TRL_POLICY_ROWS + TRL_MOVE_ROW(m)) * TRL_POLICY_COLS + TRL_MOVE_COL(m);
-                const float *row = head_w + (size_t)idx * feat_dim;
-                float a = 0.f;
-                for (int i = lane; i < feat_dim; i += 64) a = fmaf(row[i], sh.xs[i], a);
+            if (MODE == 2) {
+                float xr[9];
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
-                a += head_b[idx];
-                if (lane == 0) sh.pf[k] = a;
-                lmax = fmaxf(lmax, a);
+                for (int t = 0; t < 9; t++) xr[t] = (lane + 64 * t < 521) ? sh.xs[lane + 64 * t] : 0.f;
+                for (int k0 = wave * 4; k0 < n; k0 += (BLOCK / 64) * 4) {          // 4 moves per wave and step: 36 loads in flight
+                    float acc[4]; int idx[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        int k = k0 + u < n ? k0 + u : n - 1;
+                        int m = lm[k];
+                        idx[u] = (TRL_MOVE_PLANE(m) * TRL_POLICY_ROWS + TRL_MOVE_ROW(m)) * TRL_POLICY_COLS + TRL_MOVE_COL(m);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const float *row = head_w + (size_t)idx[u] * 521;
+                        float a = 0.f;
+#pragma unroll
+                        for (int t = 0; t < 9; t++) a = fmaf((lane + 64 * t < 521) ? row[lane + 64 * t] : 0.f, xr[t], a);
+                        acc[u] = a;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        float a = acc[u];
+#pragma unroll
+                        for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+                        a += head_b[idx[u]];
+                        if (k0 + u < n) { if (lane == 0) sh.pf[k0 + u] = a; lmax = fmaxf(lmax, a); }
+                    }
+                }
+            } else {
+                for (int k = wave; k < n; k += BLOCK / 64) {
+                    int m = lm[k];
+                    int idx = (TRL_MOVE_PLANE(m) * TRL_POLICY_ROWS + TRL_MOVE_ROW(m)) * TRL_POLICY_COLS + TRL_MOVE_COL(m);
+                    const float *row = head_w + (size_t)idx * feat_dim;
+                    float a = 0.f;
+#pragma unroll 4
+                    for (int i = lane; i < feat_dim; i += 64) a = fmaf(row[i], sh.xs[i], a);
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
+                    a += head_b[idx];
+                    if (lane == 0) sh.pf[k] = a;
+                    lmax = fmaxf(lmax, a);
+                }
             }
             if (lane == 0) sh.red_f[wave] = lmax;
             __syncthreads();
