@@ -232,6 +232,11 @@ class Engine:
     def mcts_create(self, cfg):
         self._rec_cap = cfg.record_capacity if cfg.record_capacity > 0 else 16384
         _check(self._L, self._L.trl_mcts_create(self._h, C.byref(cfg)), "trl_mcts_create")
+        # persistent page-locked staging buffer for record drains (allocating / faulting it per drain costs more
+        # than the copy)
+        import torch
+        self._rec_pinned = torch.empty(self._rec_cap * RECORD_DTYPE.itemsize, dtype=torch.uint8, pin_memory=True)
+        self._rec_buf = self._rec_pinned.numpy().view(RECORD_DTYPE)
 
     def mcts_select(self, grids_ptr, vec_ptr):
         _check(self._L, self._L.trl_mcts_select(self._h, grids_ptr, vec_ptr), "trl_mcts_select")
@@ -253,7 +258,7 @@ class Engine:
                "trl_mcts_expand_head")
 
     def mcts_drain_records(self):
-        buf = np.empty(self._rec_cap, dtype=RECORD_DTYPE)
+        buf = self._rec_buf
         n = C.c_int(0)
         _check(self._L, self._L.trl_mcts_drain_records(self._h, buf.ctypes.data, self._rec_cap, C.byref(n)),
                "trl_mcts_drain_records")
