@@ -33,6 +33,8 @@ struct MgScratch {
     uint16_t flagp[4][MAP_H];      // placements reached by a rotation (rotation_just_occurred)
     uint16_t ulp[4][MAP_H];        // ... whose last writer used the last kick of its list
     uint16_t queue[QCAP];          // mx:4 | my:6 | rot:2 | flag:1 | last_kick:1
+    uint16_t edge[MAP_H];          // edge-cell mask of each row of the flood in progress
+    uint16_t task[MAP_H * MAP_W];  // its edge cells in (row, column) order: my:6 | mx:4
 };
 
 // ---- wave helpers -------------------------------------------------------------------------
@@ -180,13 +182,12 @@ static __device__ int movegen_wave(const uint16_t *rows, int type, bool need_spa
             int fmx = uni(__shfl(mx, first, 64)), fmy = uni(__shfl(my, first, 64)), frot = uni(__shfl(rot, first, 64));
             if (!((S.valid[frot][fmy] >> fmx) & 1)) continue;                          // :406-407
 
-            // scanline flood fill of this rotation state, one row per iteration (:409-425, :485-488)
+            // (1) scanline flood fill of this rotation state, one row per iteration (:409-425, :485-488); wave-uniform.
+            //     The kick probes of the reference's inner loop only read the OTHER rotations' visited maps, which
+            //     this item does not change, so they are deferred until the whole flood is known.
             uint32_t r = 1u << fmx;
-            const int col = lane / 3, dir = lane - col * 3 + 1;        // kick probe owned by this lane
-            const int nrot = (frot + dir) & 3;
-            const uint64_t kt = C_KICK[ktab + frot * 3 + (dir - 1)];
-            const int nk = (int)(kt >> 60);
-            for (int fy = fmy; fy < MAP_H && r; ++fy) {
+            int nrows = 0;
+            for (int fy = fmy; fy < MAP_H && r; ++fy, ++nrows) {
                 uint32_t vr = S.valid[frot][fy];
                 uint32_t unvis = vr & ~(uint32_t)S.visited[frot][fy];
                 r = row_fill(unvis, r);
@@ -197,9 +198,37 @@ static __device__ int movegen_wave(const uint16_t *rows, int type, bool need_spa
                 if (lane == 0) {
                     S.visited[frot][fy] |= (uint16_t)r;
                     S.present[frot][fy] |= (uint16_t)blocked_down;                     // :439-440
+                    S.edge[nrows] = (uint16_t)edges;
                 }
-                // kick probes of this row: lane = 3 * column + (direction - 1)  (:443-481)
-                bool probe = check_rot && lane < 3 * MAP_W && ((edges >> col) & 1);
+                r = r & next_vr & ~next_vis;
+            }
+            wave_sync();
+            if (!check_rot) continue;
+            // (2) edge cells of all rows, compacted in (row, column) order: lane = row
+            int n_edges;
+            {
+                uint32_t e = (lane < nrows) ? (uint32_t)S.edge[lane] : 0u;
+                int cnt = __popc(e);
+                int incl = wave_incl_scan(cnt, lane);
+                int off = incl - cnt;
+                n_edges = uni(__shfl(incl, 63, 64));
+                while (e) {
+                    int c = __ffs((int)e) - 1; e &= e - 1;
+                    S.task[off++] = (uint16_t)(((fmy + lane) << 4) | c);
+                }
+            }
+            wave_sync();
+            // (3) kick probes (:443-481), one (edge cell, direction) per lane, 64 per pass, in the reference's order
+            const int n_tasks = 3 * n_edges;
+            for (int t0 = 0; t0 < n_tasks; t0 += 64) {
+                const int t = t0 + lane;
+                const bool probe = t < n_tasks;
+                const int ei = t / 3, dir = t - ei * 3 + 1;
+                const uint32_t ed = probe ? (uint32_t)S.task[ei] : 0u;
+                const int col = ed & 15, fy = ed >> 4;
+                const int nrot = (frot + dir) & 3;
+                const uint64_t kt = C_KICK[ktab + frot * 3 + (dir - 1)];
+                const int nk = (int)(kt >> 60);
                 bool found = false, done = false;
                 int nmx = 0, nmy = 0, kidx = 0;
 #pragma unroll
@@ -227,9 +256,8 @@ static __device__ int movegen_wave(const uint16_t *rows, int type, bool need_spa
                     if (tail > QCAP) { *overflow = 1; tail = QCAP; }
                 }
                 emit_flagged(S, found && tvis && tstuck, nrot, nmy, nbit, nul, lane);   // :474-480
-                wave_sync();
-                r = r & next_vr & ~next_vis;
             }
+            wave_sync();
         }
 
         // placements -> policy planes -> ascending move list (:650-749, ai.py:1016-1024)
