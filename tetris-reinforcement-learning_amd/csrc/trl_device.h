@@ -26,7 +26,7 @@ constexpr int QCAP  = 1024;        // FIFO capacity per search (observed max 511
 constexpr int SPAWN_Y = TRL_ROWS - TRL_SPAWN_ROW;   // 17
 
 // LDS scratch of one wavefront's search
-struct MgScratch {
+struct alignas(4) MgScratch {
     uint16_t valid[4][MAP_H];      // valid[r][ym] bit xm: piece (rotation r) at origin (xm-2, ym-2) fits
     uint16_t visited[4][MAP_H];
     uint16_t present[4][MAP_H];    // unflagged placements
@@ -114,20 +114,43 @@ __device__ __forceinline__ uint32_t row_fill(uint32_t m, uint32_t seed) {
 }
 
 // ---- flagged placements, kept in the reference's "last flagged writer wins" order ------------
-// (move_generation.py:671-677: unique_placements[key] = loc whenever loc is flagged)
-__device__ __forceinline__ void emit_flagged(MgScratch &S, bool emit, int rot, int my, uint32_t bit, int ul, int lane) {
+// (move_generation.py:671-677: unique_placements[key] = loc whenever loc is flagged).  The emitting lanes of one
+// call are in the reference's order; per key only the LAST of them decides the last-kick bit.  "Am I the last
+// emitter of my key" is settled in registers (one readlane per emitter), then every deciding lane updates the
+// planes at once with LDS atomics on the 32-bit words holding the 16-bit row masks.
+__device__ __forceinline__ void emit_flagged(MgScratch &S, bool emit, int rot, int my, uint32_t bit, int ul, int lane, bool isT) {
     uint64_t m = __ballot(emit);
-    while (m) {
-        int l = __ffsll((unsigned long long)m) - 1;
-        m &= m - 1;
-        if (lane == l) {
-            S.flagp[rot][my] |= (uint16_t)bit;
-            uint16_t u = S.ulp[rot][my];
-            S.ulp[rot][my] = ul ? (uint16_t)(u | bit) : (uint16_t)(u & ~bit);
+    if (!m) return;
+    const int idx = rot * MAP_H + my;
+    const uint32_t wbit = bit << ((idx & 1) * 16);
+    unsigned int *fw = reinterpret_cast<unsigned int *>(&S.flagp[0][0]) + (idx >> 1);
+    if (!isT) {                                   // only T planes look at the flags: any order
+        if (emit) atomicOr(fw, wbit);
+    } else {
+        const int key = (idx << 4) | (31 - __clz((int)bit));
+        bool last = emit;
+        for (uint64_t mm = m; mm; mm &= mm - 1) {
+            const int l = __ffsll((unsigned long long)mm) - 1;
+            const int kl = __builtin_amdgcn_readlane(key, l);
+            if (key == kl && lane < l) last = false;
         }
-        wave_sync();
+        if (last) {
+            unsigned int *uw = reinterpret_cast<unsigned int *>(&S.ulp[0][0]) + (idx >> 1);
+            atomicOr(fw, wbit);
+            if (ul) atomicOr(uw, wbit); else atomicAnd(uw, ~wbit);
+        }
     }
+    wave_sync();
 }
+
+#ifdef TRL_PROFILE
+static __device__ unsigned long long g_prof[16];
+#define PROF_T(v) unsigned long long v = __builtin_readcyclecounter()
+#define PROF_ADD(i, a, b) do { prof_acc[i] += (b) - (a); } while (0)
+#else
+#define PROF_T(v)
+#define PROF_ADD(i, a, b)
+#endif
 
 // ---- the search: _generate_moves_for_piece + _convolutional_algorithm +
 //      _convert_placements_to_policy (move_generation.py:107-153, 325-488, 650-749) -----------
@@ -137,6 +160,10 @@ __device__ __forceinline__ void emit_flagged(MgScratch &S, bool emit, int rot, i
 // *overflow is set when a cap was hit.
 static __device__ int movegen_wave(const uint16_t *rows, int type, bool need_spawn, MgScratch &S,
                             uint16_t *out, int out_cap, int lane, int *overflow) {
+#ifdef TRL_PROFILE
+    unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    PROF_T(p0);
     // validity maps + clear planes
     for (int i = lane; i < 4 * MAP_H; i += 64) {
         int r = i / MAP_H, ym = i - r * MAP_H;
@@ -151,6 +178,7 @@ static __device__ int movegen_wave(const uint16_t *rows, int type, bool need_spa
     int sx = spawn_x(type);
     wave_sync();
 
+    PROF_T(p1); PROF_ADD(0, p0, p1);
     bool ok = (S.valid[0][sy + 2] >> (sx + 2)) & 1;                                  // :349-351
     if (need_spawn) ok = ok && ((S.valid[0][SPAWN_Y + 2] >> (sx + 2)) & 1);           // player.py:40
     ok = uni(ok);
@@ -164,18 +192,21 @@ static __device__ int movegen_wave(const uint16_t *rows, int type, bool need_spa
         wave_sync();
 
         while (head < tail) {
+            PROF_T(q0);
             // classify up to 64 queued items at once
             int idx = head + lane;
             bool act = idx < tail;
-            uint32_t it = act ? S.queue[idx] : 0u;
+            uint32_t it = S.queue[act ? idx : head];
             int mx = it & 15, my = (it >> 4) & 63, rot = (it >> 10) & 3, fl = (it >> 12) & 1, ul = (it >> 13) & 1;
             uint32_t bit = 1u << mx;
-            bool vis = act && (S.visited[rot][my] & bit);
-            bool stuck = (my + 1 >= MAP_H) || !(S.valid[rot][my + 1 < MAP_H ? my + 1 : my] & bit);
+            const uint32_t cv = S.visited[rot][my], cb = S.valid[rot][my + 1 < MAP_H ? my + 1 : my];
+            bool vis = act & ((cv & bit) != 0);
+            bool stuck = (my + 1 >= MAP_H) | ((cb & bit) == 0);
             uint64_t unv = __ballot(act && !vis);
             int first = unv ? (__ffsll((unsigned long long)unv) - 1) : 64;
             // items up to and including the first unvisited one are popped now (:382-398)
-            emit_flagged(S, act && lane <= first && fl && stuck, rot, my, bit, ul, lane);
+            emit_flagged(S, act & (lane <= first) & (fl != 0) & stuck, rot, my, bit, ul, lane, type == PT);
+            PROF_T(q1); PROF_ADD(1, q0, q1); PROF_ADD(8, 0ull, 1ull);
             if (first == 64) { int n = tail - head; head += (n < 64 ? n : 64); continue; }
             head += first + 1;
 
@@ -203,6 +234,7 @@ static __device__ int movegen_wave(const uint16_t *rows, int type, bool need_spa
                 r = r & next_vr & ~next_vis;
             }
             wave_sync();
+            PROF_T(q2); PROF_ADD(2, q1, q2); PROF_ADD(9, 0ull, (unsigned long long)nrows);
             if (!check_rot) continue;
             // (2) edge cells of all rows, compacted in (row, column) order: lane = row
             int n_edges;
@@ -218,34 +250,44 @@ static __device__ int movegen_wave(const uint16_t *rows, int type, bool need_spa
                 }
             }
             wave_sync();
+            PROF_T(q3); PROF_ADD(3, q2, q3);
             // (3) kick probes (:443-481), one (edge cell, direction) per lane, 64 per pass, in the reference's order
             const int n_tasks = 3 * n_edges;
+            // the three kick lists of this rotation: wave-uniform (scalar) loads, selected per lane below
+            const uint64_t kt1 = C_KICK[ktab + frot * 3 + 0], kt2 = C_KICK[ktab + frot * 3 + 1], kt3 = C_KICK[ktab + frot * 3 + 2];
             for (int t0 = 0; t0 < n_tasks; t0 += 64) {
                 const int t = t0 + lane;
                 const bool probe = t < n_tasks;
                 const int ei = t / 3, dir = t - ei * 3 + 1;
-                const uint32_t ed = probe ? (uint32_t)S.task[ei] : 0u;
-                const int col = ed & 15, fy = ed >> 4;
+                const uint32_t ed = S.task[probe ? ei : 0];                // unconditional LDS reads throughout: one
+                const int col = ed & 15, fy = ed >> 4;                     // round trip per stage instead of one per probe
                 const int nrot = (frot + dir) & 3;
-                const uint64_t kt = C_KICK[ktab + frot * 3 + (dir - 1)];
+                const uint64_t kt = dir == 1 ? kt1 : (dir == 2 ? kt2 : kt3);
                 const int nk = (int)(kt >> 60);
-                bool found = false, done = false;
-                int nmx = 0, nmy = 0, kidx = 0;
+                const uint16_t *vrow = S.valid[nrot];
+                int txs[6], tys[6]; uint32_t vv[6];
 #pragma unroll
                 for (int ki = 0; ki < 6; ki++) {
-                    int kx = (int)((kt >> (6 * ki)) & 7) - 2, ky = (int)((kt >> (6 * ki + 3)) & 7) - 2;
-                    int tx = col + kx, ty = fy - ky;
-                    bool in = (unsigned)tx < (unsigned)MAP_W && (unsigned)ty < (unsigned)MAP_H;
-                    bool fit = in && ((S.valid[nrot][in ? ty : 0] >> (in ? tx : 0)) & 1);
-                    if (probe && !done && ki < nk && fit) {
-                        done = true; found = (ty >= 2);                                 // new_y < 0: discard (:462-463)
-                        nmx = tx; nmy = ty; kidx = ki;
-                    }
+                    txs[ki] = col + (int)((kt >> (6 * ki)) & 7) - 2;
+                    tys[ki] = fy - ((int)((kt >> (6 * ki + 3)) & 7) - 2);
+                    int tyc = tys[ki] < 0 ? 0 : (tys[ki] > MAP_H - 1 ? MAP_H - 1 : tys[ki]);
+                    vv[ki] = vrow[tyc];
                 }
+                int found_i = 0, nmx = 0, nmy = 0, kidx = 0, done = 0;
+#pragma unroll
+                for (int ki = 0; ki < 6; ki++) {
+                    int in = (int)((unsigned)txs[ki] < (unsigned)MAP_W) & (int)((unsigned)tys[ki] < (unsigned)MAP_H);
+                    int fit = in & (int)((vv[ki] >> (txs[ki] & 15)) & 1) & (int)(ki < nk) & (int)probe & (done ^ 1);
+                    found_i = fit ? (int)(tys[ki] >= 2) : found_i;                      // new_y < 0: discard (:462-463)
+                    nmx = fit ? txs[ki] : nmx; nmy = fit ? tys[ki] : nmy; kidx = fit ? ki : kidx;
+                    done |= fit;
+                }
+                const bool found = found_i != 0;
                 int nul = (isT && dir != 2 && kidx == nk - 1) ? 1 : 0;
                 uint32_t nbit = 1u << nmx;
-                bool tvis = found && (S.visited[nrot][nmy] & nbit);
-                bool tstuck = (nmy + 1 >= MAP_H) || !(S.valid[nrot][nmy + 1 < MAP_H ? nmy + 1 : nmy] & nbit);
+                const uint32_t tv = S.visited[nrot][nmy], tb = vrow[nmy + 1 < MAP_H ? nmy + 1 : nmy];
+                bool tvis = found & ((tv & nbit) != 0);
+                bool tstuck = (nmy + 1 >= MAP_H) | ((tb & nbit) == 0);
                 bool push = found && !tvis;
                 uint64_t pm = __ballot(push);
                 if (pm) {
@@ -255,10 +297,12 @@ static __device__ int movegen_wave(const uint16_t *rows, int type, bool need_spa
                     tail += __popcll(pm);
                     if (tail > QCAP) { *overflow = 1; tail = QCAP; }
                 }
-                emit_flagged(S, found && tvis && tstuck, nrot, nmy, nbit, nul, lane);   // :474-480
+                emit_flagged(S, found && tvis && tstuck, nrot, nmy, nbit, nul, lane, isT);   // :474-480
             }
             wave_sync();
+            PROF_T(q4); PROF_ADD(4, q3, q4); PROF_ADD(10, 0ull, (unsigned long long)((n_tasks + 63) / 64));
         }
+        PROF_T(c0);
 
         // placements -> policy planes -> ascending move list (:650-749, ai.py:1016-1024)
         const int nrotp = C_NROT[type], base = C_PLANE_BASE[type];
@@ -294,8 +338,13 @@ static __device__ int movegen_wave(const uint16_t *rows, int type, bool need_spa
             }
         }
         if (total > out_cap) { *overflow = 1; total = out_cap; }
+        PROF_T(c1); PROF_ADD(5, c0, c1);
     }
     wave_sync();
+    PROF_T(pz); PROF_ADD(6, p0, pz); PROF_ADD(11, 0ull, 1ull);
+#ifdef TRL_PROFILE
+    if (lane == 0) for (int i = 0; i < 12; i++) atomicAdd(&g_prof[i], prof_acc[i]);
+#endif
     return total;
 }
 

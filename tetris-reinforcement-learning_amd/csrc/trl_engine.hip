@@ -283,6 +283,14 @@ int trl_last_kernel_ms(trl_engine *h, float *ms_out) {
     return TRL_OK;
 }
 
+#ifdef TRL_PROFILE
+int trl_debug_prof(unsigned long long *host_out, int reset) {
+    HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(trl::g_prof), sizeof(unsigned long long) * 16));
+    if (reset) { unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(trl::g_prof), z, sizeof z)); }
+    return TRL_OK;
+}
+#endif
+
 // test hook (declared in tests only): integer attack formulas, rows int16[n][8] -> out int16[n][4]
 int trl_debug_attack_table(const int16_t *host_rows, int n, int16_t *host_out) {
     int16_t *d_rows = nullptr, *d_out = nullptr;
