@@ -34,7 +34,6 @@ struct alignas(4) MgScratch {
     uint16_t ulp[4][MAP_H];        // ... whose last writer used the last kick of its list
     uint16_t queue[QCAP];          // mx:4 | my:6 | rot:2 | flag:1 | last_kick:1
     uint16_t edge[MAP_H];          // edge-cell mask of each row of the flood in progress
-    uint16_t task[MAP_H * MAP_W];  // its edge cells in (row, column) order: my:6 | mx:4
 };
 
 // ---- wave helpers -------------------------------------------------------------------------
@@ -158,7 +157,7 @@ static __device__ unsigned long long g_prof[16];
 // hold / next (Player.create_piece must succeed, player.py:37-44).  Writes the encoded
 // placements of this piece type in ascending order to out[] and returns their number;
 // *overflow is set when a cap was hit.
-static __device__ int movegen_wave(const uint16_t *rows, int type, bool need_spawn, MgScratch &S,
+static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int type, bool need_spawn, MgScratch &S,
                             uint16_t *out, int out_cap, int lane, int *overflow) {
 #ifdef TRL_PROFILE
     unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -187,6 +186,7 @@ static __device__ int movegen_wave(const uint16_t *rows, int type, bool need_spa
         const bool check_rot = (type != PO);
         const bool isT = (type == PT);
         const int ktab = (type == PI) ? 12 : 0;
+        uint16_t *task = out;      // the move-list buffer doubles as the edge-cell list of the flood in progress (my:6 | mx:4)
         int head = 0, tail = 1;
         if (lane == 0) S.queue[0] = (uint16_t)((sx + 2) | ((sy + 2) << 4));
         wave_sync();
@@ -244,9 +244,11 @@ static __device__ int movegen_wave(const uint16_t *rows, int type, bool need_spa
                 int incl = wave_incl_scan(cnt, lane);
                 int off = incl - cnt;
                 n_edges = uni(__shfl(incl, 63, 64));
+                if (n_edges > out_cap) { *overflow = 1; n_edges = out_cap; }
                 while (e) {
                     int c = __ffs((int)e) - 1; e &= e - 1;
-                    S.task[off++] = (uint16_t)(((fmy + lane) << 4) | c);
+                    if (off < out_cap) task[off] = (uint16_t)(((fmy + lane) << 4) | c);
+                    off++;
                 }
             }
             wave_sync();
@@ -259,7 +261,7 @@ static __device__ int movegen_wave(const uint16_t *rows, int type, bool need_spa
                 const int t = t0 + lane;
                 const bool probe = t < n_tasks;
                 const int ei = t / 3, dir = t - ei * 3 + 1;
-                const uint32_t ed = S.task[probe ? ei : 0];                // unconditional LDS reads throughout: one
+                const uint32_t ed = task[probe ? ei : 0];                // unconditional LDS reads throughout: one
                 const int col = ed & 15, fy = ed >> 4;                     // round trip per stage instead of one per probe
                 const int nrot = (frot + dir) & 3;
                 const uint64_t kt = dir == 1 ? kt1 : (dir == 2 ? kt2 : kt3);
@@ -365,7 +367,7 @@ __device__ __forceinline__ void update_b2b_level(trl_player_state &p) {      // 
     p.b2b_level = (uint8_t)lvl;
 }
 // floor(q(1 + c/4)) style terms are evaluated as integer products over 4 or 8
-static __device__ int get_attack(trl_player_state &p, int ruleset, int rows, bool tspin, bool mini, bool all_clear) {
+static __device__ __forceinline__ int get_attack(trl_player_state &p, int ruleset, int rows, bool tspin, bool mini, bool all_clear) {
     int attack = 0;
     if (rows == 0) {
         p.combo = 0;
@@ -455,7 +457,7 @@ __device__ __forceinline__ bool garbage_push(trl_player_state &p, int col, int n
 }
 
 // Queue.generate_bag + Game.add_bag_to_all (piece_queue.py:17-21, game.py:34-38)
-static __device__ void add_bag_to_all(trl_game_state &g, uint64_t seed) {
+static __device__ __forceinline__ void add_bag_to_all(trl_game_state &g, uint64_t seed) {
     for (int i = 0; i < 2; i++) {
         uint64_t k = g.bag_ctr++;
         uint32_t bag = 0x6543210u;                       // nibble j = j
@@ -472,7 +474,7 @@ static __device__ void add_bag_to_all(trl_game_state &g, uint64_t seed) {
 }
 
 // Game.setup (game.py:28-32) on a zeroed slot
-static __device__ void game_setup(trl_game_state &g, int ruleset, uint64_t seed, uint32_t stream) {
+static __device__ __forceinline__ void game_setup(trl_game_state &g, int ruleset, uint64_t seed, uint32_t stream) {
     uint64_t *w = reinterpret_cast<uint64_t *>(&g);
     for (int i = 0; i < (int)(sizeof(trl_game_state) / 8); i++) w[i] = 0;
     g.stream = stream; g.ruleset = (uint8_t)ruleset;
@@ -484,7 +486,7 @@ static __device__ void game_setup(trl_game_state &g, int ruleset, uint64_t seed,
 // Game.make_move(move, add_bag, add_history=False)  (game.py:40-98, player.py:109-188)
 // `gctr`: running garbage-draw counter to use instead of the state's own (search-time copies
 // draw from the real game's stream, as the reference draws from one global generator)
-static __device__ void make_move(trl_game_state &g, uint64_t seed, int move, bool add_bag, uint32_t *gctr = nullptr) {
+static __device__ __forceinline__ void make_move(trl_game_state &g, uint64_t seed, int move, bool add_bag, uint32_t *gctr = nullptr) {
     uint32_t &garb_ctr = gctr ? *gctr : g.garb_ctr;
     trl_player_state &p = g.p[g.turn];
     trl_player_state &o = g.p[1 - g.turn];

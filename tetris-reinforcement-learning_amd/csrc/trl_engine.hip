@@ -28,7 +28,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset(trl_game_state *states, const u
     states[g] = st;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_legal(trl_game_state *states, uint16_t *counts, uint16_t *moves) {
+__global__ __launch_bounds__(BLOCK, 8) void k_legal(trl_game_state *states, uint16_t *counts, uint16_t *moves) {
     __shared__ BlockShared sh;
     const int tid = threadIdx.x, game = blockIdx.x;
     load_state(sh, states + game, tid);
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(trl_game_state *states, const ui
 }
 
 // C2 workload: n_plies x { legal -> uniform pick -> make_move(add_bag) -> re-setup when finished }
-__global__ __launch_bounds__(BLOCK) void k_rollout(trl_game_state *states, uint64_t seed, int n_plies, int max_plies,
+__global__ __launch_bounds__(BLOCK, 8) void k_rollout(trl_game_state *states, uint64_t seed, int n_plies, int max_plies,
                                                    unsigned long long *steps_total) {
     __shared__ BlockShared sh;
     const int tid = threadIdx.x, game = blockIdx.x;

@@ -37,7 +37,7 @@ __device__ __forceinline__ void store_state(const BlockShared &sh, trl_game_stat
 
 // legal placements of the side to move into sh.list / sh.cnt; all 128 threads call it.
 // Returns (uniformly) the total count; list order = slot sh.order first.
-static __device__ int block_movegen(BlockShared &sh, int tid) {
+static __device__ __forceinline__ int block_movegen(BlockShared &sh, int tid) {
     const int wave = tid >> 6, lane = tid & 63;
     if (tid == 0) { sh.overflow = 0; sh.cnt[0] = 0; sh.cnt[1] = 0; sh.order = 0; }
     __syncthreads();
