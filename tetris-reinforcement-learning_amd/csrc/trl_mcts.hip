@@ -291,7 +291,7 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
             int w = g.p[0].game_over ? 1 : (g.p[1].game_over ? 0 : -1);      // Game.winner, game.py:217-225
             c.terminal_value = (w == g.turn) ? 1.0 : (w == 1 - g.turn) ? 0.0 : 0.5;
         }
-        if (sh.b.overflow) c.overflow = 1;
+        if (kind == 0 && sh.b.overflow) { c.overflow = 1; atomicAdd(&M.counters[5], 1ull); }     // a legal-move cap was hit
         M.ctl[slot] = c;
         atomicAdd(&M.counters[0], 1ull);
     }
@@ -787,7 +787,6 @@ int trl_mcts_create(trl_engine *h, const trl_mcts_config *cfg) {
     d.cfg = *cfg;
     d.n_games = h->cfg.n_games;
     d.seed = h->cfg.seed;
-    d.max_nodes = cfg->max_nodes > 0 ? cfg->max_nodes : DEFAULT_MAX_NODES;
     d.rec_cap = cfg->record_capacity > 0 ? cfg->record_capacity : DEFAULT_REC_CAP;
     int longest = cfg->max_iter;
     if (cfg->training && cfg->use_playout_cap) {
@@ -796,6 +795,9 @@ int trl_mcts_create(trl_engine *h, const trl_mcts_config *cfg) {
         if (longest < cfg->max_iter) longest = cfg->max_iter;
     }
     d.cap_states = longest + 2;
+    // default tree capacity: one expansion per simulation, ~50 children each (measured: 20.5 k nodes after 400
+    // simulations), with headroom; never below 65 536
+    d.max_nodes = cfg->max_nodes > 0 ? cfg->max_nodes : (longest * 96 > DEFAULT_MAX_NODES ? longest * 96 : DEFAULT_MAX_NODES);
     size_t nn = (size_t)d.n_games * d.max_nodes, n = (size_t)d.n_games;
     HIPCHK(hipMalloc(&d.t.parent, nn * 4)); HIPCHK(hipMalloc(&d.t.first, nn * 4)); HIPCHK(hipMalloc(&d.t.visit, nn * 4));
     HIPCHK(hipMalloc(&d.t.state, nn * 4)); HIPCHK(hipMalloc(&d.t.nchild, nn * 2)); HIPCHK(hipMalloc(&d.t.move, nn * 2));

@@ -34,18 +34,35 @@ constexpr int TRUNK_THREADS = 256;
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-// one 3x3 conv over the tiles of this wave: acc[s] (+)= conv(buf)[tile s]
+// one 3x3 conv over the tiles of this wave: acc[s] (+)= conv(buf)[tile s], s = 0..5 (tiles wave + 4 s), and this
+// wave's quarter of the K range of tile 24 (25 tiles do not divide by 4 waves: the odd tile is split over the
+// 36 K-steps, 9 per wave, and summed through LDS -- every wave then carries 6.25 tiles instead of 7/6/6/6)
+template <int W>
+__device__ __forceinline__ void partial24(const float *buf, const float (&w)[36], int b24, int g, f32x4 &acc) {
+#pragma unroll
+    for (int tap = (9 * W) / 4; tap <= (9 * W + 8) / 4; tap++) {
+        const int off = ((tap / 3) * PW + (tap % 3)) * STRIDE + 4 * g;
+        f32x4 a = *reinterpret_cast<const f32x4 *>(buf + b24 + off);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int ks = tap * 4 + j;
+            if (ks >= 9 * W && ks < 9 * W + 9) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], w[ks], acc, 0, 0, 0);
+        }
+    }
+}
+
 template <bool INIT_BIAS>
-__device__ __forceinline__ void conv3x3(const float *buf, const float *wp, float bias, const int (&base)[7], int ntiles,
+__device__ __forceinline__ void conv3x3(const float *buf, const float *wp, float bias, const int (&base)[7], int wave,
                                         int g, int lane, f32x4 (&acc)[7]) {
     float w[36];
 #pragma unroll
     for (int i = 0; i < 36; i++) w[i] = wp[i * 64 + lane];
 #pragma unroll
-    for (int s = 0; s < 7; s++) {
+    for (int s = 0; s < 6; s++) {
         if (INIT_BIAS) acc[s] = f32x4{bias, bias, bias, bias};
         else acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    acc[6] = f32x4{0.f, 0.f, 0.f, 0.f};
     // tiles in pairs: two independent accumulator chains hide the 40-cycle dependent MFMA latency
 #pragma unroll
     for (int s = 0; s < 6; s += 2) {
@@ -61,39 +78,34 @@ __device__ __forceinline__ void conv3x3(const float *buf, const float *wp, float
             }
         }
     }
-    if (ntiles == 7) {
-#pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            const int off = ((tap / 3) * PW + (tap % 3)) * STRIDE + 4 * g;
-            f32x4 a0 = *reinterpret_cast<const f32x4 *>(buf + base[6] + off);
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], w[tap * 4 + j], acc[6], 0, 0, 0);
-        }
-    }
+    if (wave == 0) partial24<0>(buf, w, base[6], g, acc[6]);
+    else if (wave == 1) partial24<1>(buf, w, base[6], g, acc[6]);
+    else if (wave == 2) partial24<2>(buf, w, base[6], g, acc[6]);
+    else partial24<3>(buf, w, base[6], g, acc[6]);
 }
 
 __global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__restrict__ boards, const float *__restrict__ wts,
                                                               int n_blocks, float *__restrict__ out,
                                                               const uint8_t *__restrict__ need) {
     if (need && !need[blockIdx.x]) return;      // board whose tower output is already cached (trl_mcts_zcache)
-    __shared__ __attribute__((aligned(16))) float lds[BUF_FLOATS + BW * BH];
-    float *bufA = lds, *brd = lds + BUF_FLOATS;
+    __shared__ __attribute__((aligned(16))) float lds[BUF_FLOATS + BW * BH + 4 * 256];
+    float *bufA = lds, *brd = lds + BUF_FLOATS, *part = lds + BUF_FLOATS + BW * BH;      // part: K-split partials of tile 24
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, co = lane & 15;
     const size_t board = blockIdx.x;
 
-    for (int i = tid; i < BUF_FLOATS + BW * BH; i += TRUNK_THREADS) lds[i] = 0.f;
+    for (int i = tid; i < BUF_FLOATS + BW * BH + 4 * 256; i += TRUNK_THREADS) lds[i] = 0.f;
     __syncthreads();
     for (int i = tid; i < 400; i += TRUNK_THREADS) brd[(i / 10 + 2) * BW + (i % 10) + 2] = boards[board * 400 + i];
     __syncthreads();
 
     // tiles of this wave: T = wave + 4 s.  A-operand row of a lane: position 16 T + (lane & 15);
     // C/D rows of a lane: positions 16 T + 4 g + r, r = 0..3, column = output channel `co`.
-    const int ntiles = (wave == 0) ? 7 : 6;
+    // slot 6 is tile 24 for every wave: wave 0 owns its outputs (C/D layout), all four waves share its K range
     int base[7];                    // float offset of the 3x3 window's top-left in a padded buffer (A operand)
 #pragma unroll
     for (int s = 0; s < 7; s++) {
-        int T = wave + 4 * s; if (T >= NT) T = NT - 1;
+        int T = (s < 6) ? wave + 4 * s : NT - 1;
         int p = 16 * T + (lane & 15);
         base[s] = ((p / 10) * PW + (p % 10)) * STRIDE;
     }
@@ -135,8 +147,16 @@ __global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__res
             }
         }
         __syncthreads();
-        conv3x3<true>(bufA, wb + 32, bias_a, base, ntiles, g, lane, acc);
+        conv3x3<true>(bufA, wb + 32, bias_a, base, wave, g, lane, acc);
+        *reinterpret_cast<f32x4 *>(part + wave * 256 + lane * 4) = acc[6];
         __syncthreads();                              // every wave has read its halo: the buffer can be overwritten
+        if (wave == 0) {
+            f32x4 t = *reinterpret_cast<const f32x4 *>(part + lane * 4);
+            t += *reinterpret_cast<const f32x4 *>(part + 256 + lane * 4);
+            t += *reinterpret_cast<const f32x4 *>(part + 512 + lane * 4);
+            t += *reinterpret_cast<const f32x4 *>(part + 768 + lane * 4);
+            acc[6] = t + f32x4{bias_a, bias_a, bias_a, bias_a};
+        }
 #pragma unroll
         for (int s = 0; s < 7; s++) {
             int T = wave + 4 * s;
@@ -149,10 +169,18 @@ __global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__res
             }
         }
         __syncthreads();
-        conv3x3<false>(bufA, wb + 32 + 2304 + 16, 0.f, base, ntiles, g, lane, acc);
+        conv3x3<false>(bufA, wb + 32 + 2304 + 16, 0.f, base, wave, g, lane, acc);
 #pragma unroll
-        for (int s = 0; s < 7; s++) x[s] += acc[s];
+        for (int s = 0; s < 6; s++) x[s] += acc[s];
+        *reinterpret_cast<f32x4 *>(part + wave * 256 + lane * 4) = acc[6];
         __syncthreads();
+        if (wave == 0) {
+            f32x4 t = *reinterpret_cast<const f32x4 *>(part + lane * 4);
+            t += *reinterpret_cast<const f32x4 *>(part + 256 + lane * 4);
+            t += *reinterpret_cast<const f32x4 *>(part + 512 + lane * 4);
+            t += *reinterpret_cast<const f32x4 *>(part + 768 + lane * 4);
+            x[6] += t;
+        }
     }
 
     // tail: relu(bn(x)) -> 1x1 conv over the 16 channels (= 16 lanes) -> folded bn -> relu
