@@ -483,24 +483,31 @@ static __device__ __forceinline__ void game_setup(trl_game_state &g, int ruleset
     for (int i = 0; i < 2; i++) create_next_piece(g.p[i]);
 }
 
-// Game.make_move(move, add_bag, add_history=False)  (game.py:40-98, player.py:109-188)
+// Game.make_move(move, add_bag, add_history=False)  (game.py:40-98, player.py:109-188), one wavefront.
+// All 64 lanes call it with the same arguments; `g` lives in LDS.  Rows are spread over the lanes: the
+// hard-drop row is a ballot of "piece fits at origin row = lane" (no drop loop), cleared rows are found and
+// compacted with one ballot + popcount, pending garbage is inserted by a parallel row shift; lane 0 keeps the
+// scalar bookkeeping (hold, attack, queues, spawn).
 // `gctr`: running garbage-draw counter to use instead of the state's own (search-time copies
 // draw from the real game's stream, as the reference draws from one global generator)
-static __device__ __forceinline__ void make_move(trl_game_state &g, uint64_t seed, int move, bool add_bag, uint32_t *gctr = nullptr) {
-    uint32_t &garb_ctr = gctr ? *gctr : g.garb_ctr;
+static __device__ __forceinline__ void make_move(trl_game_state &g, uint64_t seed, int move, bool add_bag, int lane,
+                                                 uint32_t *gctr = nullptr) {
     trl_player_state &p = g.p[g.turn];
     trl_player_state &o = g.p[1 - g.turn];
     // Game.move_piece (game.py:40-64)
-    int pc = C_PLANE[TRL_MOVE_PLANE(move)];
-    int type = pc & 7, rot = (pc >> 3) & 3, ts = pc >> 5;
-    int x = TRL_MOVE_COL(move) - 2, y = TRL_MOVE_ROW(move);
-    if (p.piece == P_NONE || type != p.piece) hold_piece(p);
-    bool rot_flag = ts >= 1, last_kick = ts == 2;
+    const int pc = C_PLANE[TRL_MOVE_PLANE(move)];
+    int type = pc & 7;
+    const int rot = (pc >> 3) & 3, ts = pc >> 5;
+    const int x = TRL_MOVE_COL(move) - 2, y = TRL_MOVE_ROW(move);
+    if (lane == 0 && (p.piece == P_NONE || type != p.piece)) hold_piece(p);
+    wave_sync();
     if (p.game_over) return;                                                    // game.py:70
     type = p.piece;
-    // Player.place_piece (player.py:109-188)
-    int place_y = y;                                                            // ghost_y, player.py:46-59
-    while (pose_fits(p.rows, type, x, place_y + 1, rot)) place_y++;
+    bool rot_flag = ts >= 1, last_kick = ts == 2;
+    // Player.place_piece (player.py:109-188).  ghost_y (player.py:46-59): rows the piece fits at, one per lane
+    const uint64_t vm = __ballot(lane < TRL_ROWS && pose_fits(p.rows, type, x, lane, rot));
+    const int place_y = y + (__ffsll((unsigned long long)(~vm >> (y + 1))) - 1);
+    if (!((vm >> place_y) & 1)) { if (lane == 0) g.flags |= TRL_FLAG_BADMOVE; wave_sync(); return; }   // not a legal pose
     if (y != place_y) { rot_flag = false; last_kick = false; }                  // :115-118
     bool tspin = false, mini = false, all_clear = false;
     if (type == PT && rot_flag) {                                               // :127-140
@@ -511,56 +518,62 @@ static __device__ __forceinline__ void make_move(trl_game_state &g, uint64_t see
         if (!front && !last_kick) mini = true;
     }
     if (g.ruleset == TRL_RULESET_S2 && !tspin) {                                // :143-151 (pose at the move's y)
-        bool mobile = pose_fits(p.rows, type, x - 1, y, rot) || pose_fits(p.rows, type, x + 1, y, rot) ||
-                      pose_fits(p.rows, type, x, y - 1, rot) || pose_fits(p.rows, type, x, y + 1, rot);
+        bool up = y >= 1 && ((vm >> (y - 1)) & 1), down = (vm >> (y + 1)) & 1;
+        bool mobile = up || down || pose_fits(p.rows, type, x - 1, y, rot) || pose_fits(p.rows, type, x + 1, y, rot);
         if (!mobile) mini = true;
     }
-    if (!pose_fits(p.rows, type, x, place_y, rot)) { g.flags |= TRL_FLAG_BADMOVE; return; }   // not a legal pose
-    uint32_t mm = C_MINO[type * 4 + rot];                                       // :153-157 lock
-    uint64_t touched = 0;
-    for (int i = 0; i < 4; i++) {
-        int col = x + (int)((mm >> (4 * i)) & 3), row = place_y + (int)((mm >> (4 * i + 2)) & 3);
-        p.rows[row] |= (uint16_t)(1u << col);
-        touched |= 1ull << row;
-    }
-    p.piece = P_NONE;
-    int cleared = 0;                                                            // :161-175
-    uint64_t full = 0;
-    for (uint64_t t = touched; t; t &= t - 1) {
-        int row = __ffsll((unsigned long long)t) - 1;
-        if (p.rows[row] == 0x3FF) { full |= 1ull << row; cleared++; }
-    }
-    if (cleared) {
-        int dst = TRL_ROWS - 1;
-        for (int r = TRL_ROWS - 1; r >= 0; r--)
-            if (!((full >> r) & 1)) { p.rows[dst] = p.rows[r]; dst--; }
-        for (; dst >= 0; dst--) p.rows[dst] = 0;
-        uint32_t any = 0;                                                       // :177-178
-        for (int r = 0; r < TRL_ROWS; r++) any |= p.rows[r];
-        all_clear = (any == 0);
-    }
-    int attack = get_attack(p, g.ruleset, cleared, tspin, mini, all_clear);     // :180-186
-    p.pieces += 1;
-    // garbage_to_send = [column] * attack, then Game.check_garbage (game.py:100-117)
-    int send = attack, column = 0;
-    if (attack > 0) column = (int)rng_below(seed, g.stream, TRL_RNG_GARBAGE, garb_ctr++, 10);
-    int cancel = send < (int)p.garbage_len ? send : (int)p.garbage_len;
-    if (cancel > 0) { garbage_pop(p, cancel); send -= cancel; }
-    if (p.garbage_len > 0 && cleared == 0) {                                    // spawn_garbage, board.py:12-21
-        int n = p.garbage_len;
-        if (n > TRL_ROWS) { g.flags |= TRL_FLAG_OVERFLOW; n = TRL_ROWS; }
-        for (int r = 0; r < TRL_ROWS - n; r++) p.rows[r] = p.rows[r + n];
-        for (int i = 0; i < n; i++) {
-            int c = (int)((p.garbage[i >> 4] >> (4 * (i & 15))) & 15);
-            p.rows[TRL_ROWS - n + i] = (uint16_t)(0x3FFu & ~(1u << c));
+    if (lane == 0) {                                                            // :153-157 lock
+        uint32_t mm = C_MINO[type * 4 + rot];
+        for (int i = 0; i < 4; i++) {
+            int col = x + (int)((mm >> (4 * i)) & 3), row = place_y + (int)((mm >> (4 * i + 2)) & 3);
+            p.rows[row] |= (uint16_t)(1u << col);
         }
-        p.garbage[0] = p.garbage[1] = p.garbage[2] = p.garbage[3] = 0; p.garbage_len = 0;
+        p.piece = P_NONE;
     }
-    if (send > 0 && garbage_push(o, column, send)) g.flags |= TRL_FLAG_OVERFLOW;
-    create_next_piece(p);                                                       // game.py:80
-    if (add_bag && p.queue_len < 5) add_bag_to_all(g, seed);                    // game.py:82-83
-    g.turn ^= 1;
-    g.ply++;
+    wave_sync();
+    // :161-178 full rows -> delete + zero rows on top; a surviving row r moves down by the full rows below it
+    const uint32_t v = lane < TRL_ROWS ? (uint32_t)p.rows[lane < TRL_ROWS ? lane : 0] : 0u;
+    const bool full = v == 0x3FFu;
+    const uint64_t fm = __ballot(full);
+    const int cleared = __popcll(fm);
+    if (cleared) {
+        all_clear = __ballot(!full && v != 0) == 0;
+        wave_sync();
+        if (lane < TRL_ROWS && !full) p.rows[lane + __popcll(fm >> (lane + 1))] = (uint16_t)v;
+        if (lane < cleared) p.rows[lane] = 0;
+        wave_sync();
+    }
+    if (lane == 0) {
+        uint32_t &garb_ctr = gctr ? *gctr : g.garb_ctr;
+        int attack = get_attack(p, g.ruleset, cleared, tspin, mini, all_clear);     // :180-186
+        p.pieces += 1;
+        // garbage_to_send = [column] * attack, then Game.check_garbage (game.py:100-117)
+        int send = attack, column = 0;
+        if (attack > 0) column = (int)rng_below(seed, g.stream, TRL_RNG_GARBAGE, garb_ctr++, 10);
+        int cancel = send < (int)p.garbage_len ? send : (int)p.garbage_len;
+        if (cancel > 0) { garbage_pop(p, cancel); send -= cancel; }
+        if (send > 0 && garbage_push(o, column, send)) g.flags |= TRL_FLAG_OVERFLOW;
+    }
+    wave_sync();
+    int n = p.garbage_len;
+    if (n > 0 && cleared == 0) {                                                // spawn_garbage, board.py:12-21
+        if (n > TRL_ROWS) { if (lane == 0) g.flags |= TRL_FLAG_OVERFLOW; n = TRL_ROWS; }
+        const uint32_t w = lane < TRL_ROWS ? (uint32_t)p.rows[lane < TRL_ROWS ? lane : 0] : 0u;
+        const int c = (int)((p.garbage[(lane & 63) >> 4] >> (4 * (lane & 15))) & 15);
+        wave_sync();
+        if (lane >= n && lane < TRL_ROWS) p.rows[lane - n] = (uint16_t)w;
+        if (lane < n) p.rows[TRL_ROWS - n + lane] = (uint16_t)(0x3FFu & ~(1u << c));
+        wave_sync();
+        if (lane == 0) { p.garbage[0] = p.garbage[1] = p.garbage[2] = p.garbage[3] = 0; p.garbage_len = 0; }
+    }
+    wave_sync();
+    if (lane == 0) {
+        create_next_piece(p);                                                   // game.py:80
+        if (add_bag && p.queue_len < 5) add_bag_to_all(g, seed);                // game.py:82-83
+        g.turn ^= 1;
+        g.ply++;
+    }
+    wave_sync();
 }
 
 __device__ __forceinline__ bool is_terminal(const trl_game_state &g) { return g.p[0].game_over || g.p[1].game_over; }

@@ -55,10 +55,10 @@ __global__ __launch_bounds__(BLOCK) void k_step(trl_game_state *states, const ui
         for (int i = tid; i < total; i += BLOCK) mine |= (merged_move(sh, i) == move);
         legal = __syncthreads_or(mine);
     }
-    if (tid == 0) {
-        if (legal) make_move(sh.g, seed, move, add_bag != 0);
-        else sh.g.flags |= TRL_FLAG_BADMOVE;
-        if (check_legal && sh.overflow) sh.g.flags |= TRL_FLAG_OVERFLOW;
+    if (tid < 64) {
+        if (legal) make_move(sh.g, seed, move, add_bag != 0, tid);
+        else if (tid == 0) sh.g.flags |= TRL_FLAG_BADMOVE;
+        if (tid == 0 && check_legal && sh.overflow) sh.g.flags |= TRL_FLAG_OVERFLOW;
     }
     __syncthreads();
     store_state(sh, states + game, tid);
@@ -74,15 +74,17 @@ __global__ __launch_bounds__(BLOCK, 8) void k_rollout(trl_game_state *states, ui
     int steps = 0;
     for (int k = 0; k < n_plies; k++) {
         int total = block_movegen(sh, tid);
-        if (tid == 0) {
+        if (tid < 64) {
             trl_game_state &g = sh.g;
-            if (sh.overflow) g.flags |= TRL_FLAG_OVERFLOW;
+            if (tid == 0 && sh.overflow) g.flags |= TRL_FLAG_OVERFLOW;
             if (total > 0) {
-                int idx = (int)rng_below(seed, g.stream, TRL_RNG_POLICY, g.pol_ctr++, (uint32_t)total);
-                make_move(g, seed, merged_move(sh, idx), true);
+                int idx = (int)rng_below(seed, g.stream, TRL_RNG_POLICY, g.pol_ctr, (uint32_t)total);
+                wave_sync();
+                if (tid == 0) g.pol_ctr++;
+                make_move(g, seed, merged_move(sh, idx), true, tid);
                 steps++;
             }
-            if (total == 0 || is_terminal(g) || (int)g.ply >= max_plies) {
+            if (tid == 0 && (total == 0 || is_terminal(g) || (int)g.ply >= max_plies)) {
                 uint32_t stream = g.stream + 0x01000000u, episode = g.episode + 1;
                 int ruleset = g.ruleset; uint8_t flags = g.flags;
                 game_setup(g, ruleset, seed, stream);

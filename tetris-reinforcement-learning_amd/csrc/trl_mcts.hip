@@ -221,10 +221,12 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
         pstate = M.t.state[nb + par];
         copy_state(&sh.b.g, pool + M.t.state[nb + par], tid);
         __syncthreads();
-        if (tid == 0) {
+        if (tid < 64) {
             uint32_t gctr = real[slot].garb_ctr;               // the reference draws from one global stream
-            make_move(sh.b.g, M.seed, M.t.move[nb + node], false, &gctr);
-            real[slot].garb_ctr = gctr;
+            make_move(sh.b.g, M.seed, M.t.move[nb + node], false, tid, &gctr);
+            if (tid == 0) real[slot].garb_ctr = gctr;
+        }
+        if (tid == 0) {
             int s = M.t.state[nb + node];
             if (s < 0) { s = sh.ctl.n_states++; M.t.state[nb + node] = s; }
             M.t.turn[nb + node] = sh.b.g.turn;
@@ -637,11 +639,11 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
             }
         }
         __syncthreads();
+        if (tid < 64 && sh.chosen >= 0) make_move(sh.g, M.seed, sh.chosen, true, tid);   // game.make_move(move), ai.py:1668
         if (tid == 0) {
             trl_game_state &g = sh.g;
             bool over = true;
             if (sh.chosen >= 0) {
-                make_move(g, M.seed, sh.chosen, true);                        // game.make_move(move), ai.py:1668
                 // while not terminal and len(history.states) < MAX_MOVES  (history: 1 + player-1 placements)
                 over = is_terminal(g) || (1 + g.p[1].pieces) >= TRL_MAX_MOVES;
             }
