@@ -210,3 +210,34 @@ def test_call_order_errors():
         e.legal_moves()
     with pytest.raises(trl.EngineError):
         e.rollout_random(1)
+
+
+def test_device_pointer_entry_points():
+    """trl_env_legal_dev / trl_env_step_dev / trl_env_state_dev: the same results with the buffers left in HBM
+    (wrapped as torch tensors through __cuda_array_interface__) as with the host-copy variants"""
+    import torch
+    from tetris_rl_amd.gating import _DevView
+    n = 64
+    a = trl.Engine(n, seed=SEED); a.reset(); a.rollout_random(20)
+    b = trl.Engine(n, seed=SEED); b.reset(); b.rollout_random(20)
+    cnt, mv = a.legal_moves()
+    L = trl.load_library()
+    pc, pm, ps = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert L.trl_env_legal_moves(b._h, None, None) == 0            # results stay on the device
+    assert L.trl_env_legal_dev(b._h, C.byref(pc), C.byref(pm)) == 0 and L.trl_env_state_dev(b._h, C.byref(ps)) == 0
+    torch.cuda.synchronize()                                       # device-wide: covers the engine's stream
+    dev = torch.device("cuda", 0)
+    tc = torch.as_tensor(_DevView(pc.value, (n,), "<i2"), device=dev)
+    tm = torch.as_tensor(_DevView(pm.value, (n, 512), "<i2"), device=dev)
+    assert np.array_equal(tc.cpu().numpy().view(np.uint16), cnt)
+    got = tm.cpu().numpy().view(np.uint16)
+    for g in range(n):
+        assert np.array_equal(got[g, :cnt[g]], mv[g, :cnt[g]])
+    pick = mv[np.arange(n), (np.arange(n) * 5) % np.maximum(cnt, 1)].copy()
+    a.step(pick)
+    dpick = torch.from_numpy(pick.view(np.int16)).to(dev)
+    torch.cuda.synchronize()
+    assert L.trl_env_step_dev(b._h, dpick.data_ptr(), 1, 1) == 0
+    torch.cuda.synchronize()
+    ts = torch.as_tensor(_DevView(ps.value, (n, 320), "|u1"), device=dev)
+    assert np.array_equal(ts.cpu().numpy(), a.get_state())
