@@ -317,6 +317,13 @@ int  trl_alphasame_trunk16(const float *dev_boards, int n_boards, const float *d
 /* same, skipping the boards whose dev_need[board] is 0 (their dev_out rows are left untouched) */
 int  trl_alphasame_trunk16_need(const float *dev_boards, int n_boards, const float *dev_packed, int n_blocks,
                                 float *dev_out, const uint8_t *dev_need, void *stream);
+/* the same tower for filters in {16, 32, 64} (BASELINE config C5 is 20 blocks x 64 filters): F = filters,
+ * G = F/16 channel groups and N-tiles.  dev_packed: conv1 [F][25]; per block s1[F] t1[F] Wa ba[F] Wb with a 3x3
+ * conv packed as [G channel groups][9 taps][4 j][G N-tiles][64 lanes] = W[16 ntile + lane%16][16 cg + 4 (lane/16) + j][tap]
+ * (the B operands of v_mfma_f32_16x16x4_f32; at F = 16 this is the trunk16 layout); tail s[F] t[F] wk[F] bk, then
+ * >= 16 KiB of padding (the weight prefetch of the last conv runs one step ahead).  dev_need may be NULL. */
+int  trl_alphasame_trunk(const float *dev_boards, int n_boards, const float *dev_packed, int filters, int n_blocks,
+                         float *dev_out, const uint8_t *dev_need, void *stream);
 
 #ifdef __cplusplus
 }

@@ -118,7 +118,7 @@ def test_fused_hip_tower_matches_torch_tower(golden_dir):
     outputs of magnitude ~1 (different summation order only)."""
     d = np.load(os.path.join(golden_dir, "net.npz"))
     net = load_net(d, "b10f16", 10, 16, device="cuda")
-    assert net._folded["packed16"] is not None
+    assert net._folded["packed_tower"] is not None
     g = torch.Generator().manual_seed(3)
     m = 515
     boards = (torch.rand((m, 1, 40, 10), generator=g) < torch.rand((m, 1, 1, 1), generator=g)).float()
@@ -133,6 +133,32 @@ def test_fused_hip_tower_matches_torch_tower(golden_dir):
     assert a.shape == b.shape == (m, 400)
     assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max()))
     assert float(b.abs().max()) > 0.01
+
+
+@pytest.mark.parametrize("tag,blocks,filters", [("b3f64", 3, 64), ("b2f32", 2, 32)])
+def test_wide_fused_tower(golden_dir, tag, blocks, filters):
+    """k_trunk_wide<32/64>: (1) the reference's logits and values of the fixture positions within 1e-5 through
+    the HIP tower, (2) against the PyTorch tower on random boards, (3) the need flags skip boards"""
+    d = np.load(os.path.join(golden_dir, "net_wide.npz"))
+    net = load_net(d, tag, blocks, filters, device="cuda")
+    assert net._folded["packed_tower"] is not None and net.supports_tower_cache
+    grids, vec = packed_features(d["states"])
+    v, logits = net.heads(torch.from_numpy(grids).cuda(), torch.from_numpy(vec).cuda())
+    assert np.abs(torch.sigmoid(v).cpu().numpy() - d["%s/values" % tag]).max() < TOL
+    assert np.abs(logits.cpu().numpy() - d["%s/logits" % tag]).max() < TOL
+    g = torch.Generator().manual_seed(5)
+    m = 301
+    boards = (torch.rand((m, 1, 40, 10), generator=g) < torch.rand((m, 1, 1, 1), generator=g)).float()
+    boards[0] = 0; boards[1] = 1
+    boards = boards.cuda()
+    a = net.trunk(boards)
+    net.use_hip_trunk = False
+    b = net.trunk(boards)
+    net.use_hip_trunk = True
+    assert float((a - b).abs().max()) < 2e-5 * max(1.0, float(b.abs().max())) and float(b.abs().max()) > 0.01
+    need = (torch.arange(m) % 3 != 0).to(torch.uint8).cuda()
+    c = net._trunk_hip(boards, net._folded["packed_tower"], need)
+    assert torch.equal(c[need.bool()], a[need.bool()]) and not c[~need.bool()].any()
 
 
 def test_legal_only_policy_head_matches_full_softmax_path():
@@ -189,15 +215,15 @@ def test_baseresnet_selfplay_and_wide_policy_head():
 
 
 def test_c5_configuration_runs():
-    """BASELINE config C5 in miniature: 20-block / 64-filter AlphaSame (PyTorch tower: the fused HIP tower is
-    the 16-filter one), MAX_ITER=800 with forced playouts + policy-target pruning; a few ticks of 32 slots"""
+    """BASELINE config C5 in miniature: 20-block / 64-filter AlphaSame on the fused 64-filter HIP tower,
+    MAX_ITER=800 with forced playouts + policy-target pruning; a few ticks of 32 slots"""
     torch.manual_seed(0)
     mc = trl.AlphaSameConfig(blocks=20, filters=64)
     net = trl.AlphaSame(mc)
     cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=800, training=True,
                      use_forced_playouts_and_policy_target_pruning=True)
     sp = trl.SelfPlay(cfg, net, 32, seed=1)
-    assert sp.net._folded["packed16"] is None
+    assert sp.net._folded["packed_tower"] is not None
     sp.tick(24)
     st = sp.stats()
     assert st["simulations"] == 24 * 32 and st["overflow"] == 0

@@ -66,6 +66,17 @@ def test_logits_and_value_match_reference(golden_dir, tag, blocks, filters):
     assert np.abs(out_v.numpy().reshape(-1) - d["%s/values" % tag]).max() < TOL
 
 
+@pytest.mark.parametrize("tag,blocks,filters", [("b3f64", 3, 64), ("b2f32", 2, 32)])
+def test_wide_towers_match_reference(golden_dir, tag, blocks, filters):
+    """32 / 64-filter AlphaSame (BASELINE config C5 is 20 x 64) against the reference's outputs"""
+    d = np.load(os.path.join(golden_dir, "net_wide.npz"))
+    net = load_net(d, tag, blocks, filters)
+    grids, vec = packed_features(d["states"])
+    v, logits = net.heads(torch.from_numpy(grids), torch.from_numpy(vec))
+    assert np.abs(torch.sigmoid(v).numpy() - d["%s/values" % tag]).max() < TOL
+    assert np.abs(logits.numpy() - d["%s/logits" % tag]).max() < TOL
+
+
 def test_reference_checkpoint_roundtrip(tmp_path, golden_dir):
     d = np.load(os.path.join(golden_dir, "net.npz"))
     net = load_net(d, "b2f8", 2, 8)

@@ -197,6 +197,176 @@ __global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__res
     }
 }
 
+
+// ---- wide tower: 32 / 64 filters (BASELINE config C5: 20 blocks x 64 filters) ------------------------------------
+// Same algorithm and data layout as k_trunk16, generalised over the channel count FF (a multiple of 16):
+//   * the activations are CG = FF/16 planes of [42 x 12 padded positions][16 channels] in LDS (FF = 64: 126 KB,
+//     one board per CU; FF = 32: 63 KB, two boards per CU), so the A fragment of (tap, channel group) is the same
+//     conflict-free ds_read_b128 as in the 16-filter kernel;
+//   * 2 NN waves (NN = FF/16 N-tiles): wave = ntile + NN * mq owns the 16 output channels of N-tile `ntile` for the
+//     even (mq = 0: 13) or odd (mq = 1: 12) M-tiles; FF = 64 -> 8 waves, 25 tiles per SIMD; two waves per SIMD
+//     either way (256 VGPRs each);
+//   * a conv's B operand is 9 FF x FF floats (147 KB at FF = 64): too large for registers, so it streams from
+//     L2 one (tap, channel group) step ahead of the MFMAs -- 4 VGPRs per step, reused by every M-tile of the wave
+//     (52 MFMAs per 1 KB of weights);
+//   * residual stream and accumulators stay in registers in MFMA C/D layout (2 x 52 VGPRs at FF = 64).
+// Per board at FF = 64, 20 blocks: 40 convs x 100 (M,N) tiles x 144 K-steps = 576 000 MFMAs = 1.18 GFLOP.
+template <int FF> struct Wide {
+    static constexpr int NN = FF / 16, CG = FF / 16, WAVES = 2 * NN, MSPLIT = 2, TS = (NT + MSPLIT - 1) / MSPLIT;
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int PLANE = BUF_FLOATS;
+    static constexpr int LDS_FLOATS = CG * PLANE + BW * BH;
+    static constexpr int CONVW = 9 * FF * FF;
+    static constexpr int WBLOCKW = 3 * FF + 2 * CONVW;
+};
+
+template <int FF, int S0, int S1>
+__device__ __forceinline__ void conv_wide_group(const float *pl, const float (&w)[4], const int (&base)[Wide<FF>::TS], int off,
+                                                f32x4 (&acc)[Wide<FF>::TS]) {
+    f32x4 a[S1 - S0];
+#pragma unroll
+    for (int s = S0; s < S1; s++) a[s - S0] = *reinterpret_cast<const f32x4 *>(pl + base[s] + off);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {           // S1 - S0 independent accumulator chains per K-step
+#pragma unroll
+        for (int s = S0; s < S1; s++) acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s - S0][j], w[j], acc[s], 0, 0, 0);
+    }
+}
+
+// acc[0 .. NTL) += conv3x3(planes)[tiles of this wave]; NTL = 13 (even tiles) or 12 (odd tiles)
+template <int FF, int NTL>
+__device__ __forceinline__ void conv_wide(const float *lds, const float *wq, const int (&base)[Wide<FF>::TS], int g,
+                                       f32x4 (&acc)[Wide<FF>::TS]) {
+    using W = Wide<FF>;
+    constexpr int WSTEP = W::NN * 64;
+    float wn[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) wn[j] = wq[j * WSTEP];
+    for (int cg = 0; cg < W::CG; cg++) {
+        const float *pl = lds + cg * W::PLANE + 4 * g;
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            float w[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) w[j] = wn[j];
+            wq += 4 * WSTEP;                          // next (tap, channel group); the last prefetch of a conv reads the
+#pragma unroll                                        // first words of what follows it in the packed buffer (unused)
+            for (int j = 0; j < 4; j++) wn[j] = wq[j * WSTEP];
+            const int off = ((tap / 3) * PW + (tap % 3)) * STRIDE;
+            constexpr int H = (NTL + 1) / 2;
+            conv_wide_group<FF, 0, H>(pl, w, base, off, acc);
+            conv_wide_group<FF, H, NTL>(pl, w, base, off, acc);
+        }
+    }
+}
+
+template <int FF>
+__global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float *__restrict__ boards,
+                                                                     const float *__restrict__ wts, int n_blocks,
+                                                                     float *__restrict__ out,
+                                                                     const uint8_t *__restrict__ need) {
+    using W = Wide<FF>;
+    constexpr int TS = W::TS, NN = W::NN, MSPLIT = W::MSPLIT, THREADS = W::THREADS;
+    if (need && !need[blockIdx.x]) return;
+    __shared__ __attribute__((aligned(16))) float lds[W::LDS_FLOATS];
+    float *brd = lds + W::CG * W::PLANE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, co = lane & 15;
+    const int ntile = wave % NN, mq = wave / NN;
+    const int ch = ntile * 16 + co;
+    const size_t board = blockIdx.x;
+
+    for (int i = tid; i < W::LDS_FLOATS; i += THREADS) lds[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < 400; i += THREADS) brd[(i / 10 + 2) * BW + (i % 10) + 2] = boards[board * 400 + i];
+    __syncthreads();
+
+    // slot s of this wave is M-tile mq + 2 s (slot 12 of the odd waves does not exist: clamped here, never computed)
+    int base[TS];
+#pragma unroll
+    for (int s = 0; s < TS; s++) {
+        int T = mq + MSPLIT * s; if (T >= NT) T = NT - 1;
+        int p = 16 * T + (lane & 15);
+        base[s] = ((p / 10) * PW + (p % 10)) * STRIDE;
+    }
+
+    f32x4 x[TS];
+    {
+        float w1[25];
+#pragma unroll
+        for (int i = 0; i < 25; i++) w1[i] = wts[ch * 25 + i];
+#pragma unroll
+        for (int s = 0; s < TS; s++) {
+            int T = mq + MSPLIT * s; if (T >= NT) T = NT - 1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int p = 16 * T + 4 * g + r, py = p / 10, px = p % 10;
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < 25; k++) a = fmaf(w1[k], brd[(py + k / 5) * BW + px + (k % 5)], a);
+                x[s][r] = a;
+            }
+        }
+    }
+
+    float *own = lds + ntile * W::PLANE + co;          // this lane's output channel inside its plane
+    const float *wb = wts + FF * 25;
+    f32x4 acc[TS];
+    // two layers per residual block, one loop body for both (the conv code exists once per tile count)
+    for (int layer = 0; layer < 2 * n_blocks; layer++) {
+        const bool first = !(layer & 1);
+        float sc = 1.f, sh = 0.f, bias = 0.f;
+        if (first) { sc = wb[ch]; sh = wb[FF + ch]; bias = wb[2 * FF + W::CONVW + ch]; }
+        // conv input -> planes (own positions): relu(bn1(x)) for the first conv, relu(previous conv) for the second
+#pragma unroll
+        for (int s = 0; s < TS; s++) {
+            int T = mq + MSPLIT * s;
+            if (T < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int p = 16 * T + 4 * g + r;
+                    float v = first ? fmaf(x[s][r], sc, sh) : acc[s][r];
+                    own[((p / 10 + 1) * PW + (p % 10) + 1) * STRIDE] = fmaxf(v, 0.f);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < TS; s++) acc[s] = f32x4{bias, bias, bias, bias};
+        const float *wq = wb + (first ? 2 * FF : 3 * FF + W::CONVW) + ntile * 64 + lane;
+        if (mq == 0) conv_wide<FF, TS>(lds, wq, base, g, acc);
+        else conv_wide<FF, NT - TS>(lds, wq, base, g, acc);
+        if (!first) {
+#pragma unroll
+            for (int s = 0; s < TS; s++) x[s] += acc[s];
+            wb += W::WBLOCKW;
+        }
+        __syncthreads();                              // every wave has read its inputs: the planes can be overwritten
+    }
+
+    // tail: relu(bn(x)) -> 1x1 conv over the FF channels (16 lanes x NN waves) -> folded bn -> relu
+    const float s = wb[ch], t = wb[FF + ch], wk = wb[2 * FF + ch], bk = wb[3 * FF];
+    float *part = lds;                                 // [NN][400] partial sums (the planes are dead now)
+#pragma unroll
+    for (int sidx = 0; sidx < TS; sidx++) {
+        int T = mq + MSPLIT * sidx;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float v = fmaxf(fmaf(x[sidx][r], s, t), 0.f) * wk;
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            if (co == 0 && T < NT) part[ntile * 400 + 16 * T + 4 * g + r] = v;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 400; i += THREADS) {
+        float v = bk;
+#pragma unroll
+        for (int n = 0; n < NN; n++) v += part[n * 400 + i];
+        out[board * 400 + i] = fmaxf(v, 0.f);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -215,6 +385,25 @@ int trl_alphasame_trunk16_need(const float *dev_boards, int n_boards, const floa
         return fail(TRL_E_INVALID, "trl_alphasame_trunk16: %s", "bad argument");
     hipLaunchKernelGGL(k_trunk16, dim3(n_boards), dim3(TRUNK_THREADS), 0, (hipStream_t)stream, dev_boards, dev_packed,
                        n_blocks, dev_out, dev_need);
+    HIPCHK(hipGetLastError());
+    return TRL_OK;
+}
+
+// process_grid of AlphaSame for filters in {16, 32, 64}, kernels = 1: the same contract as trl_alphasame_trunk16 with
+// the packed weights in the general layout of nets.AlphaSame._pack() (identical to the 16-filter layout at filters = 16).
+int trl_alphasame_trunk(const float *dev_boards, int n_boards, const float *dev_packed, int filters, int n_blocks,
+                        float *dev_out, const uint8_t *dev_need, void *stream) {
+    if (!dev_boards || !dev_packed || !dev_out || n_boards <= 0 || n_blocks < 0)
+        return fail(TRL_E_INVALID, "trl_alphasame_trunk: %s", "bad argument");
+    if (filters == 16) return trl_alphasame_trunk16_need(dev_boards, n_boards, dev_packed, n_blocks, dev_out, dev_need, stream);
+    if (filters == 32)
+        hipLaunchKernelGGL(k_trunk_wide<32>, dim3(n_boards), dim3(Wide<32>::THREADS), 0, (hipStream_t)stream, dev_boards, dev_packed,
+                           n_blocks, dev_out, dev_need);
+    else if (filters == 64)
+        hipLaunchKernelGGL(k_trunk_wide<64>, dim3(n_boards), dim3(Wide<64>::THREADS), 0, (hipStream_t)stream, dev_boards, dev_packed,
+                           n_blocks, dev_out, dev_need);
+    else
+        return fail(TRL_E_INVALID, "trl_alphasame_trunk: %s", "the fused tower exists for 16, 32 and 64 filters");
     HIPCHK(hipGetLastError());
     return TRL_OK;
 }

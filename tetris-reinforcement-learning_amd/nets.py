@@ -72,7 +72,7 @@ class AlphaSame(nn.Module):
                                          "1": nn.BatchNorm1d(mc.value_head_neurons),
                                          "3": nn.Linear(mc.value_head_neurons, 1)})
         self._folded = None
-        self.use_hip_trunk = True       # fused HIP tower when the net is on the GPU and filters == 16
+        self.use_hip_trunk = True       # fused HIP tower when the net is on the GPU and filters is 16, 32 or 64
         self.eval()
 
     # -- folding ------------------------------------------------------------------------------
@@ -94,28 +94,38 @@ class AlphaSame(nn.Module):
         fd["oside"] = ((self.osidedense["0"].weight * so.view(-1, 1)).contiguous(), (self.osidedense["0"].bias * so + to).contiguous())
         sv, tv = _affine(self.value_head["1"])
         fd["v0"] = ((self.value_head["0"].weight * sv.view(-1, 1)).contiguous(), (self.value_head["0"].bias * sv + tv).contiguous())
-        fd["packed16"] = self._pack16(fd) if (self.model_config.filters == 16 and self.conv1.weight.is_cuda) else None
+        fd["packed_tower"] = self._pack_tower(fd) if (self.model_config.filters in self.HIP_TOWER_FILTERS and self.model_config.kernels == 1
+                                              and self.conv1.weight.is_cuda) else None
         self._folded = fd
         return self
 
-    def _pack16(self, fd):
-        """weights in the layout of csrc/trl_net.hip (B operands of v_mfma_f32_16x16x4_f32)"""
-        lane = torch.arange(64, device=self.conv1.weight.device)
+    HIP_TOWER_FILTERS = (16, 32, 64)
+
+    def _pack_tower(self, fd):
+        """weights in the layout of csrc/trl_net.hip (B operands of v_mfma_f32_16x16x4_f32); filters 16, 32 or 64:
+        a 3x3 conv becomes [channel group][tap][j][N-tile][lane] = W[16 ntile + lane % 16][16 cg + 4 (lane // 16) + j][tap]"""
+        dev = self.conv1.weight.device
+        f = self.model_config.filters
+        G = f // 16
+        lane = torch.arange(64, device=dev)
         co, g = lane & 15, lane >> 4
 
-        def pack_conv(w):                       # w [16 out, 16 in, 3, 3] -> [9 taps][4 j][64 lanes]
-            w = w.reshape(16, 16, 9)
-            out = torch.empty((9, 4, 64), dtype=torch.float32, device=w.device)
-            for j in range(4):
-                out[:, j, :] = w[co, 4 * g + j, :].transpose(0, 1)
+        def pack_conv(w):                       # w [f out, f in, 3, 3]
+            w = w.reshape(f, f, 9)
+            out = torch.empty((G, 9, 4, G, 64), dtype=torch.float32, device=w.device)
+            for cg in range(G):
+                for nt in range(G):
+                    for j in range(4):
+                        out[cg, :, j, nt, :] = w[16 * nt + co, 16 * cg + 4 * g + j, :].transpose(0, 1)
             return out.reshape(-1)
 
-        parts = [self.conv1.weight.reshape(16, 25).reshape(-1)]
+        parts = [self.conv1.weight.reshape(f, 25).reshape(-1)]
         for s1, t1, wa, ba, wb in fd["blocks"]:
             parts += [s1.reshape(-1), t1.reshape(-1), pack_conv(wa), ba.reshape(-1), pack_conv(wb)]
         s, t = fd["tail"]
         wk, bk = fd["k1"]
-        parts += [s.reshape(-1), t.reshape(-1), wk.reshape(-1), bk.reshape(-1), torch.zeros(15, device=bk.device)]
+        # padding: the wide kernels prefetch the weights one K-step past the end of a conv
+        parts += [s.reshape(-1), t.reshape(-1), wk.reshape(-1), bk.reshape(-1), torch.zeros(15 + (0 if f == 16 else 4096), device=dev)]
         return torch.cat([p.to(torch.float32) for p in parts]).contiguous()
 
     def load_state_dict(self, *a, **k):
@@ -133,8 +143,8 @@ class AlphaSame(nn.Module):
     def trunk(self, boards):
         """boards float[m, 1, 40, 10] -> float[m, 400] (process_grid of the reference, architectures.py:121-127)"""
         fd = self._folded or self.prepare()._folded
-        if fd["packed16"] is not None and self.use_hip_trunk:
-            return self._trunk_hip(boards, fd["packed16"])
+        if fd["packed_tower"] is not None and self.use_hip_trunk:
+            return self._trunk_hip(boards, fd["packed_tower"])
         x = F.conv2d(boards, self.conv1.weight, padding=2)
         for s1, t1, wa, ba, wb in fd["blocks"]:
             h = torch.relu(x * s1 + t1)
@@ -155,18 +165,18 @@ class AlphaSame(nn.Module):
             out = torch.empty((m, ROWS * COLS), dtype=torch.float32, device=boards.device)
         else:
             out = torch.zeros((m, ROWS * COLS), dtype=torch.float32, device=boards.device)
-        rc = L.trl_alphasame_trunk16_need(x.data_ptr(), m, packed.data_ptr(), len(self.res_blocks), out.data_ptr(),
-                                          None if need is None else need.data_ptr(),
-                                          torch.cuda.current_stream(boards.device).cuda_stream)
+        rc = L.trl_alphasame_trunk(x.data_ptr(), m, packed.data_ptr(), self.model_config.filters, len(self.res_blocks),
+                                   out.data_ptr(), None if need is None else need.data_ptr(),
+                                   torch.cuda.current_stream(boards.device).cuda_stream)
         if rc != 0:
-            raise _eng.EngineError("trl_alphasame_trunk16 failed: %s" % L.trl_last_error().decode())
+            raise _eng.EngineError("trl_alphasame_trunk failed: %s" % L.trl_last_error().decode())
         return out
 
     @property
     def supports_tower_cache(self):
         """True when the tower runs as the fused HIP kernel, which can skip boards (trl_mcts_zcache flow)"""
         fd = self._folded or self.prepare()._folded
-        return fd["packed16"] is not None and self.use_hip_trunk
+        return fd["packed_tower"] is not None and self.use_hip_trunk
 
     def device_heads(self):
         """trl_alphasame_heads for trl_mcts_expand_alphasame (pointers into the folded tensors of prepare())"""
@@ -186,7 +196,7 @@ class AlphaSame(nn.Module):
     def tower_need(self, grids, need):
         """tower outputs [2n, 400] of the boards flagged in need (uint8 [2n]); the others are zero"""
         fd = self._folded or self.prepare()._folded
-        return self._trunk_hip(grids.reshape(-1, 1, ROWS, COLS), fd["packed16"], need)
+        return self._trunk_hip(grids.reshape(-1, 1, ROWS, COLS), fd["packed_tower"], need)
 
     @torch.no_grad()
     def head_inputs(self, grids, vec, z=None):
