@@ -325,6 +325,15 @@ int  trl_alphasame_trunk16_need(const float *dev_boards, int n_boards, const flo
 int  trl_alphasame_trunk(const float *dev_boards, int n_boards, const float *dev_packed, int filters, int n_blocks,
                          float *dev_out, const uint8_t *dev_need, void *stream);
 
+/* Tower of the BaseResNet family -- the reference's current default nets (architectures.py:159-170 ResidualBlock,
+ * 173-222 BaseResNet / 308-353 AuxBaseResNet process_grid): stem conv3x3 + BN + ReLU, n_blocks post-activation
+ * residual blocks, filters in {32, 64}; followed by kout (1..8) raw 1x1 projections of the final feature map
+ * (own_collapse / opp_collapse before bias, conditioning and ReLU, which the caller applies).
+ * dev_out float[n_boards][kout][400].  dev_packed (every BN folded into its conv): stem W[F][9] b[F]; per block
+ * b1[F] W1 b2[F] W2 (3x3 convs packed as for trl_alphasame_trunk); tail Wk[kout][F]; >= 16 KiB of padding. */
+int  trl_resnet_trunk(const float *dev_boards, int n_boards, const float *dev_packed, int filters, int n_blocks, int kout,
+                      float *dev_out, const uint8_t *dev_need, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,50 @@ def main():
         out["%s/values" % tag] = np.array(values, dtype=np.float32)
         out["%s/logits" % tag] = np.stack(logits)
         print(tag, "values", np.round(values, 4), "logit range", float(np.min(logits)), float(np.max(logits)))
+    # ---- the default family at a width the fused tower covers: BaseResNet / AuxBaseResNet, 32 filters ----
+    from architectures import BaseResNet, BaseResNetConfig, AuxBaseResNet, AuxBaseResNetConfig
+    small = dict(blocks=3, filters=32, opp_hidden=16, own_kernels=4, value_hidden=8)
+    for tag, cls, mc in (("base32", BaseResNet, BaseResNetConfig(**small)),
+                         ("aux32", AuxBaseResNet, AuxBaseResNetConfig(aux_hidden=8, **small))):
+        torch.manual_seed(11)
+        net = cls(mc)
+        g = torch.Generator().manual_seed(78)
+        head_in = mc.own_kernels * 400 + 49 + 3 + 1
+        with torch.no_grad():
+            for name, mod in net.named_modules():
+                if isinstance(mod, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)):
+                    mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.1)
+                    mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+                    mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) * 0.4 + 0.8)
+                    mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * 0.05)
+            w, b = net_fixture.policy_head(in_features=head_in)
+            net.policy_head.weight.copy_(torch.from_numpy(w))
+            net.policy_head.bias.copy_(torch.from_numpy(b))
+        net.eval()
+        sd = net.state_dict()
+        for k, v in sd.items():
+            if not k.startswith("policy_head."):
+                out["%s/%s" % (tag, k)] = v.numpy()
+        out["%s/keys" % tag] = np.array(list(sd.keys()))
+        values, logits, auxs = [], [], []
+        for st in states:
+            game, rng, ply = gg.game_from_state(bytes(st))
+            X = []
+            for feature in ai.game_to_X(game):
+                t = torch.tensor(feature)
+                if t.size() == (40, 10):
+                    t = t.unsqueeze(dim=0).type(torch.float)
+                X.append(t.unsqueeze(dim=0))
+            with torch.no_grad():
+                o = net.forward(*X)
+            values.append(float(o[0].item())); logits.append(o[1].reshape(-1).numpy().copy())
+            if len(o) == 3:
+                auxs.append(o[2].reshape(-1).numpy().copy())
+        out["%s/values" % tag] = np.array(values, dtype=np.float32)
+        out["%s/logits" % tag] = np.stack(logits)
+        if auxs:
+            out["%s/aux" % tag] = np.stack(auxs)
+        print(tag, "values", np.round(values, 4))
     out["torch_version"] = np.array(torch.__version__)
     np.savez_compressed(os.path.join(OUT, "net_wide.npz"), **out)
 

@@ -28,3 +28,16 @@ for hip in (True, False):
     t0 = time.perf_counter(); sp.tick(40); sp.synchronize(); dt = (time.perf_counter() - t0) / 40
     print("C5 1024 slots hip=%s: %.2f ms/tick -> %.1f moves/s at 800 sims" % (hip, dt * 1e3, 1024 / (800 * dt)), flush=True)
     del sp
+# the reference's default net: BaseResNet(8 blocks, 32 filters), evaluation of 1024 positions (2048 boards)
+mc = trl.BaseResNetConfig()
+net = trl.BaseResNet(mc).cuda().prepare()
+n = 1024
+grids = (torch.rand((2, n, 400), device="cuda") < 0.3).float()
+vec = torch.rand((n, 105), device="cuda")
+for hip in (True, False):
+    net.use_hip_trunk = hip
+    net.head_inputs(grids, vec); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10): net.head_inputs(grids, vec)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    print("BaseResNet default hip=%s: %.2f ms / %d positions" % (hip, dt * 1e3, n), flush=True)

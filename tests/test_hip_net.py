@@ -161,6 +161,35 @@ def test_wide_fused_tower(golden_dir, tag, blocks, filters):
     assert torch.equal(c[need.bool()], a[need.bool()]) and not c[~need.bool()].any()
 
 
+@pytest.mark.parametrize("tag", ["base32", "aux32"])
+def test_baseresnet_fused_tower(golden_dir, tag):
+    """trl_resnet_trunk (k_trunk_wide<32, POST>): the reference's BaseResNet / AuxBaseResNet outputs within 1e-5
+    through the fused tower, and fused == PyTorch tower on a larger random batch"""
+    from test_net_parity import load_base32
+    d, net = load_base32(golden_dir, tag, device="cuda")
+    assert net._folded["packed_tower"] is not None
+    grids, vec = packed_features(d["states"])
+    tg, tv = torch.from_numpy(grids).cuda(), torch.from_numpy(vec).cuda()
+    v, logits = net.heads(tg, tv)
+    assert np.abs(torch.sigmoid(v).cpu().numpy() - d["%s/values" % tag]).max() < TOL
+    assert np.abs(logits.cpu().numpy() - d["%s/logits" % tag]).max() < TOL
+    if tag == "aux32":
+        n = len(d["states"])
+        out = net(tg[0].reshape(n, 1, 40, 10), tv[:, :49].reshape(n, 7, 7), tv[:, 49], tv[:, 50], tv[:, 51],
+                  tg[1].reshape(n, 1, 40, 10), tv[:, 52:101].reshape(n, 7, 7), tv[:, 101], tv[:, 102], tv[:, 103], tv[:, 104])
+        assert len(out) == 3 and np.abs(out[2].cpu().numpy() - d["aux32/aux"]).max() < TOL
+    g = torch.Generator().manual_seed(9)
+    n = 150
+    big = (torch.rand((2, n, 400), generator=g) < torch.rand((2, n, 1), generator=g)).float().cuda()
+    bv = tv[torch.arange(n) % tv.shape[0]].contiguous()
+    a = net.head_inputs(big, bv)
+    net.use_hip_trunk = False
+    b = net.head_inputs(big, bv)
+    net.use_hip_trunk = True
+    assert float((a[1] - b[1]).abs().max()) < 2e-5 * max(1.0, float(b[1].abs().max()))
+    assert float((a[0] - b[0]).abs().max()) < 2e-5
+
+
 def test_legal_only_policy_head_matches_full_softmax_path():
     """trl_mcts_expand_head (logits of the legal moves only, formed in the expand kernel) against the
     reference data flow (softmax over all 11 583 logits, then gather): same root children, priors equal

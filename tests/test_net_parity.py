@@ -122,6 +122,26 @@ def test_baseresnet_family_matches_reference(golden_dir, tag):
         assert len(out) == 3 and np.abs(out[2].numpy() - d["aux/aux"]).max() < TOL
 
 
+SMALL32 = dict(blocks=3, filters=32, opp_hidden=16, own_kernels=4, value_hidden=8)
+
+
+def load_base32(golden_dir, tag, device="cpu"):
+    d = np.load(os.path.join(golden_dir, "net_wide.npz"))
+    net = (nets.BaseResNet(nets.BaseResNetConfig(**SMALL32)) if tag == "base32"
+           else nets.AuxBaseResNet(nets.AuxBaseResNetConfig(aux_hidden=8, **SMALL32)))
+    return d, _load_generic(d, tag, net).to(device).prepare()
+
+
+@pytest.mark.parametrize("tag", ["base32", "aux32"])
+def test_baseresnet_32_filters_matches_reference(golden_dir, tag):
+    """the default family at a width the fused HIP tower covers (here: its PyTorch path on the CPU)"""
+    d, net = load_base32(golden_dir, tag)
+    grids, vec = packed_features(d["states"])
+    v, logits = net.heads(torch.from_numpy(grids), torch.from_numpy(vec))
+    assert np.abs(torch.sigmoid(v).numpy() - d["%s/values" % tag]).max() < TOL
+    assert np.abs(logits.numpy() - d["%s/logits" % tag]).max() < TOL
+
+
 def test_default_size_nets_have_the_reference_key_layout(golden_dir):
     d = np.load(os.path.join(golden_dir, "net.npz"))
     for tag, net in (("base_default", nets.BaseResNet()), ("aux_default", nets.AuxBaseResNet())):

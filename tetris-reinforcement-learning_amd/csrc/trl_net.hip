@@ -233,15 +233,13 @@ __device__ __forceinline__ void conv_wide_group(const float *pl, const float (&w
     }
 }
 
-// acc[0 .. NTL) += conv3x3(planes)[tiles of this wave]; NTL = 13 (even tiles) or 12 (odd tiles)
+// acc[0 .. NTL) += conv3x3(planes)[tiles of this wave]; NTL = 13 (even tiles) or 12 (odd tiles);
+// wn = the first K-step's B operands, already in flight (loaded before the barrier that precedes the conv)
 template <int FF, int NTL>
-__device__ __forceinline__ void conv_wide(const float *lds, const float *wq, const int (&base)[Wide<FF>::TS], int g,
-                                       f32x4 (&acc)[Wide<FF>::TS]) {
+__device__ __forceinline__ void conv_wide(const float *lds, const float *wq, float (&wn)[4], const int (&base)[Wide<FF>::TS],
+                                          int g, f32x4 (&acc)[Wide<FF>::TS]) {
     using W = Wide<FF>;
     constexpr int WSTEP = W::NN * 64;
-    float wn[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) wn[j] = wq[j * WSTEP];
     for (int cg = 0; cg < W::CG; cg++) {
         const float *pl = lds + cg * W::PLANE + 4 * g;
 #pragma unroll
@@ -260,13 +258,18 @@ __device__ __forceinline__ void conv_wide(const float *lds, const float *wq, con
     }
 }
 
-template <int FF>
+// POST = false: AlphaSame (pre-activation blocks, 5x5 stem, tail BN-ReLU-1x1-BN-ReLU -> out[board][400])
+// POST = true : BaseResNet family (architectures.py:159-170, 215-222: 3x3 stem + BN + ReLU, post-activation blocks
+//               x = relu(bn2(conv2(relu(bn1(conv1(x))))) + x); tail = kout raw 1x1 projections -> out[board][kout][400],
+//               their bias / conditioning / ReLU are applied by the caller)
+template <int FF, bool POST>
 __global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float *__restrict__ boards,
                                                                      const float *__restrict__ wts, int n_blocks,
                                                                      float *__restrict__ out,
-                                                                     const uint8_t *__restrict__ need) {
+                                                                     const uint8_t *__restrict__ need, int kout) {
     using W = Wide<FF>;
-    constexpr int TS = W::TS, NN = W::NN, MSPLIT = W::MSPLIT, THREADS = W::THREADS;
+    constexpr int TS = W::TS, NN = W::NN, MSPLIT = W::MSPLIT, THREADS = W::THREADS, WSTEP = W::NN * 64;
+    constexpr int STEM = POST ? 9 : 25;
     if (need && !need[blockIdx.x]) return;
     __shared__ __attribute__((aligned(16))) float lds[W::LDS_FLOATS];
     float *brd = lds + W::CG * W::PLANE;
@@ -293,32 +296,51 @@ __global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float
 
     f32x4 x[TS];
     {
-        float w1[25];
+        float w1[STEM];
 #pragma unroll
-        for (int i = 0; i < 25; i++) w1[i] = wts[ch * 25 + i];
+        for (int i = 0; i < STEM; i++) w1[i] = wts[ch * STEM + i];
+        const float b0 = POST ? wts[FF * STEM + ch] : 0.f;
 #pragma unroll
         for (int s = 0; s < TS; s++) {
             int T = mq + MSPLIT * s; if (T >= NT) T = NT - 1;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 int p = 16 * T + 4 * g + r, py = p / 10, px = p % 10;
-                float a = 0.f;
+                float a = b0;
+                if (POST) {
 #pragma unroll
-                for (int k = 0; k < 25; k++) a = fmaf(w1[k], brd[(py + k / 5) * BW + px + (k % 5)], a);
+                    for (int k = 0; k < 9; k++) a = fmaf(w1[k], brd[(py + 1 + k / 3) * BW + px + 1 + (k % 3)], a);
+                    a = fmaxf(a, 0.f);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 25; k++) a = fmaf(w1[k], brd[(py + k / 5) * BW + px + (k % 5)], a);
+                }
                 x[s][r] = a;
             }
         }
     }
 
     float *own = lds + ntile * W::PLANE + co;          // this lane's output channel inside its plane
-    const float *wb = wts + FF * 25;
+    const float *wb = wts + FF * STEM + (POST ? FF : 0);
     f32x4 acc[TS];
     // two layers per residual block, one loop body for both (the conv code exists once per tile count)
     for (int layer = 0; layer < 2 * n_blocks; layer++) {
         const bool first = !(layer & 1);
         float sc = 1.f, sh = 0.f, bias = 0.f;
-        if (first) { sc = wb[ch]; sh = wb[FF + ch]; bias = wb[2 * FF + W::CONVW + ch]; }
-        // conv input -> planes (own positions): relu(bn1(x)) for the first conv, relu(previous conv) for the second
+        const float *wq;
+        if (POST) {                                    // block: b1[F] W1 b2[F] W2
+            bias = first ? wb[ch] : wb[FF + W::CONVW + ch];
+            wq = wb + (first ? FF : 2 * FF + W::CONVW);
+        } else {                                       // block: s1[F] t1[F] Wa ba[F] Wb
+            if (first) { sc = wb[ch]; sh = wb[FF + ch]; bias = wb[2 * FF + W::CONVW + ch]; }
+            wq = wb + (first ? 2 * FF : 3 * FF + W::CONVW);
+        }
+        wq += ntile * 64 + lane;
+        float wn[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) wn[j] = wq[j * WSTEP];
+        // conv input -> planes (own positions): the block input (pre-activation: through bn1 + relu) for the first
+        // conv, relu(previous conv) for the second
 #pragma unroll
         for (int s = 0; s < TS; s++) {
             int T = mq + MSPLIT * s;
@@ -326,7 +348,7 @@ __global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     int p = 16 * T + 4 * g + r;
-                    float v = first ? fmaf(x[s][r], sc, sh) : acc[s][r];
+                    float v = first ? (POST ? x[s][r] : fmaf(x[s][r], sc, sh)) : acc[s][r];
                     own[((p / 10 + 1) * PW + (p % 10) + 1) * STRIDE] = fmaxf(v, 0.f);
                 }
             }
@@ -334,36 +356,63 @@ __global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < TS; s++) acc[s] = f32x4{bias, bias, bias, bias};
-        const float *wq = wb + (first ? 2 * FF : 3 * FF + W::CONVW) + ntile * 64 + lane;
-        if (mq == 0) conv_wide<FF, TS>(lds, wq, base, g, acc);
-        else conv_wide<FF, NT - TS>(lds, wq, base, g, acc);
+        if (mq == 0) conv_wide<FF, TS>(lds, wq, wn, base, g, acc);
+        else conv_wide<FF, NT - TS>(lds, wq, wn, base, g, acc);
         if (!first) {
 #pragma unroll
-            for (int s = 0; s < TS; s++) x[s] += acc[s];
-            wb += W::WBLOCKW;
+            for (int s = 0; s < TS; s++) {
+                x[s] += acc[s];
+                if (POST) { x[s][0] = fmaxf(x[s][0], 0.f); x[s][1] = fmaxf(x[s][1], 0.f); x[s][2] = fmaxf(x[s][2], 0.f); x[s][3] = fmaxf(x[s][3], 0.f); }
+            }
+            wb += POST ? 2 * FF + 2 * W::CONVW : W::WBLOCKW;
         }
         __syncthreads();                              // every wave has read its inputs: the planes can be overwritten
     }
 
-    // tail: relu(bn(x)) -> 1x1 conv over the FF channels (16 lanes x NN waves) -> folded bn -> relu
-    const float s = wb[ch], t = wb[FF + ch], wk = wb[2 * FF + ch], bk = wb[3 * FF];
-    float *part = lds;                                 // [NN][400] partial sums (the planes are dead now)
+    float *part = lds;                                 // [kout][NN][400] partial sums (the planes are dead now)
+    if (POST) {
+        // tail: kout 1x1 projections of the feature map, raw
+        for (int k = 0; k < kout; k++) {
+            const float wk = wb[k * FF + ch];
 #pragma unroll
-    for (int sidx = 0; sidx < TS; sidx++) {
-        int T = mq + MSPLIT * sidx;
+            for (int sidx = 0; sidx < TS; sidx++) {
+                int T = mq + MSPLIT * sidx;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            float v = fmaxf(fmaf(x[sidx][r], s, t), 0.f) * wk;
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (co == 0 && T < NT) part[ntile * 400 + 16 * T + 4 * g + r] = v;
+                for (int r = 0; r < 4; r++) {
+                    float v = x[sidx][r] * wk;
+                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                    if (co == 0 && T < NT) part[(k * NN + ntile) * 400 + 16 * T + 4 * g + r] = v;
+                }
+            }
         }
-    }
-    __syncthreads();
-    for (int i = tid; i < 400; i += THREADS) {
-        float v = bk;
+        __syncthreads();
+        for (int i = tid; i < 400 * kout; i += THREADS) {
+            const int k = i / 400, pos = i % 400;
+            float v = 0.f;
 #pragma unroll
-        for (int n = 0; n < NN; n++) v += part[n * 400 + i];
-        out[board * 400 + i] = fmaxf(v, 0.f);
+            for (int n = 0; n < NN; n++) v += part[(k * NN + n) * 400 + pos];
+            out[(board * kout + k) * 400 + pos] = v;
+        }
+    } else {
+        // tail: relu(bn(x)) -> 1x1 conv over the FF channels (16 lanes x NN waves) -> folded bn -> relu
+        const float s = wb[ch], t = wb[FF + ch], wk = wb[2 * FF + ch], bk = wb[3 * FF];
+#pragma unroll
+        for (int sidx = 0; sidx < TS; sidx++) {
+            int T = mq + MSPLIT * sidx;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = fmaxf(fmaf(x[sidx][r], s, t), 0.f) * wk;
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                if (co == 0 && T < NT) part[ntile * 400 + 16 * T + 4 * g + r] = v;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 400; i += THREADS) {
+            float v = bk;
+#pragma unroll
+            for (int n = 0; n < NN; n++) v += part[n * 400 + i];
+            out[board * 400 + i] = fmaxf(v, 0.f);
+        }
     }
 }
 
@@ -397,13 +446,33 @@ int trl_alphasame_trunk(const float *dev_boards, int n_boards, const float *dev_
         return fail(TRL_E_INVALID, "trl_alphasame_trunk: %s", "bad argument");
     if (filters == 16) return trl_alphasame_trunk16_need(dev_boards, n_boards, dev_packed, n_blocks, dev_out, dev_need, stream);
     if (filters == 32)
-        hipLaunchKernelGGL(k_trunk_wide<32>, dim3(n_boards), dim3(Wide<32>::THREADS), 0, (hipStream_t)stream, dev_boards, dev_packed,
-                           n_blocks, dev_out, dev_need);
+        hipLaunchKernelGGL((k_trunk_wide<32, false>), dim3(n_boards), dim3(Wide<32>::THREADS), 0, (hipStream_t)stream, dev_boards,
+                           dev_packed, n_blocks, dev_out, dev_need, 1);
     else if (filters == 64)
-        hipLaunchKernelGGL(k_trunk_wide<64>, dim3(n_boards), dim3(Wide<64>::THREADS), 0, (hipStream_t)stream, dev_boards, dev_packed,
-                           n_blocks, dev_out, dev_need);
+        hipLaunchKernelGGL((k_trunk_wide<64, false>), dim3(n_boards), dim3(Wide<64>::THREADS), 0, (hipStream_t)stream, dev_boards,
+                           dev_packed, n_blocks, dev_out, dev_need, 1);
     else
         return fail(TRL_E_INVALID, "trl_alphasame_trunk: %s", "the fused tower exists for 16, 32 and 64 filters");
+    HIPCHK(hipGetLastError());
+    return TRL_OK;
+}
+
+// Tower of the BaseResNet family (architectures.py:173-353: stem conv3x3 + BN + ReLU, n_blocks post-activation residual
+// blocks) for filters in {32, 64}, followed by kout (1..8) raw 1x1 projections of the final feature map:
+// dev_out float[n_boards][kout][400].  dev_packed (batch norms folded into the convolutions): stem W[F][9] b[F];
+// per block b1[F] W1 b2[F] W2 (3x3 convs packed as for trl_alphasame_trunk); tail Wk[kout][F]; >= 16 KiB padding.
+int trl_resnet_trunk(const float *dev_boards, int n_boards, const float *dev_packed, int filters, int n_blocks, int kout,
+                     float *dev_out, const uint8_t *dev_need, void *stream) {
+    if (!dev_boards || !dev_packed || !dev_out || n_boards <= 0 || n_blocks < 0 || kout < 1 || kout > 8)
+        return fail(TRL_E_INVALID, "trl_resnet_trunk: %s", "bad argument");
+    if (filters == 32)
+        hipLaunchKernelGGL((k_trunk_wide<32, true>), dim3(n_boards), dim3(Wide<32>::THREADS), 0, (hipStream_t)stream, dev_boards,
+                           dev_packed, n_blocks, dev_out, dev_need, kout);
+    else if (filters == 64)
+        hipLaunchKernelGGL((k_trunk_wide<64, true>), dim3(n_boards), dim3(Wide<64>::THREADS), 0, (hipStream_t)stream, dev_boards,
+                           dev_packed, n_blocks, dev_out, dev_need, kout);
+    else
+        return fail(TRL_E_INVALID, "trl_resnet_trunk: %s", "the fused tower exists for 32 and 64 filters");
     HIPCHK(hipGetLastError());
     return TRL_OK;
 }

@@ -51,6 +51,21 @@ def _affine(bn):
     return s, bn.bias - bn.running_mean * s
 
 
+def _pack_conv3x3(w, f):
+    """w [f out, f in, 3, 3] -> the B operands of v_mfma_f32_16x16x4_f32 in the order csrc/trl_net.hip reads them:
+    [channel group][tap][j][N-tile][lane] = W[16 ntile + lane % 16][16 cg + 4 (lane // 16) + j][tap]"""
+    G = f // 16
+    lane = torch.arange(64, device=w.device)
+    co, g = lane & 15, lane >> 4
+    w = w.reshape(f, f, 9)
+    out = torch.empty((G, 9, 4, G, 64), dtype=torch.float32, device=w.device)
+    for cg in range(G):
+        for nt in range(G):
+            for j in range(4):
+                out[cg, :, j, nt, :] = w[16 * nt + co, 16 * cg + 4 * g + j, :].transpose(0, 1)
+    return out.reshape(-1)
+
+
 class AlphaSame(nn.Module):
     def __init__(self, model_config=None, use_tanh=False):
         super().__init__()
@@ -106,18 +121,9 @@ class AlphaSame(nn.Module):
         a 3x3 conv becomes [channel group][tap][j][N-tile][lane] = W[16 ntile + lane % 16][16 cg + 4 (lane // 16) + j][tap]"""
         dev = self.conv1.weight.device
         f = self.model_config.filters
-        G = f // 16
-        lane = torch.arange(64, device=dev)
-        co, g = lane & 15, lane >> 4
 
-        def pack_conv(w):                       # w [f out, f in, 3, 3]
-            w = w.reshape(f, f, 9)
-            out = torch.empty((G, 9, 4, G, 64), dtype=torch.float32, device=w.device)
-            for cg in range(G):
-                for nt in range(G):
-                    for j in range(4):
-                        out[cg, :, j, nt, :] = w[16 * nt + co, 16 * cg + 4 * g + j, :].transpose(0, 1)
-            return out.reshape(-1)
+        def pack_conv(w):
+            return _pack_conv3x3(w, f)
 
         parts = [self.conv1.weight.reshape(f, 25).reshape(-1)]
         for s1, t1, wa, ba, wb in fd["blocks"]:
@@ -292,9 +298,11 @@ class BaseResNet(nn.Module):
     """Inference module with the reference's parameter names (stem.0/.1, trunk.i.{conv1,bn1,conv2,bn2},
     opp_collapse, opp_encode, bias_project, own_collapse, policy_head, value_head) and the same packed
     feature interface as AlphaSame.  Every conv is followed directly by its batch norm, so all norms fold
-    into the convolutions; the tower runs as PyTorch-ROCm convolutions (no fused HIP kernel yet)."""
+    into the convolutions; on the GPU with 32 or 64 filters the tower runs as the fused HIP kernel
+    (trl_resnet_trunk, csrc/trl_net.hip), otherwise as PyTorch convolutions."""
 
     has_aux = False
+    HIP_TOWER_FILTERS = (32, 64)
 
     def __init__(self, model_config=None, use_tanh=False):
         super().__init__()
@@ -313,6 +321,7 @@ class BaseResNet(nn.Module):
         self.value_head = nn.ModuleDict({"0": nn.Linear(head_in, mc.value_hidden), "1": nn.BatchNorm1d(mc.value_hidden),
                                          "3": nn.Linear(mc.value_hidden, 1)})
         self._folded = None
+        self.use_hip_trunk = True       # fused HIP tower when the net is on the GPU and filters is 32 or 64
         self.eval()
 
     @torch.no_grad()
@@ -325,8 +334,32 @@ class BaseResNet(nn.Module):
               "v0": _fold_lin_bn(self.value_head["0"], self.value_head["1"])}
         if self.has_aux:
             fd["a0"] = _fold_lin_bn(self.aux_head["0"], self.aux_head["1"])
+        mc = self.model_config
+        fd["packed_tower"] = None
+        if mc.filters in self.HIP_TOWER_FILTERS and mc.own_kernels + 1 <= 8 and self.stem["0"].weight.is_cuda:
+            f = mc.filters
+            parts = [fd["stem"][0].reshape(-1), fd["stem"][1]]
+            for (w1, b1), (w2, b2) in fd["blocks"]:
+                parts += [b1, _pack_conv3x3(w1, f), b2, _pack_conv3x3(w2, f)]
+            # tail: the own_kernels rows of own_collapse, then the row of opp_collapse (kout = own_kernels + 1)
+            parts += [fd["own"][0].reshape(-1), fd["opp"][0].reshape(-1), torch.zeros(4096, device=fd["own"][0].device)]
+            fd["packed_tower"] = torch.cat([p.reshape(-1).to(torch.float32) for p in parts]).contiguous()
         self._folded = fd
         return self
+
+    def _tower_hip(self, boards, packed):
+        """-> float[m, own_kernels + 1, 400]: raw 1x1 projections of the final feature map (trl_resnet_trunk)"""
+        from . import engine as _eng
+        L = _eng.load_library()
+        m = boards.shape[0]
+        kout = self.model_config.own_kernels + 1
+        x = boards.reshape(m, ROWS * COLS).contiguous()
+        out = torch.empty((m, kout, ROWS * COLS), dtype=torch.float32, device=boards.device)
+        rc = L.trl_resnet_trunk(x.data_ptr(), m, packed.data_ptr(), self.model_config.filters, len(self.trunk), kout,
+                                out.data_ptr(), None, torch.cuda.current_stream(boards.device).cuda_stream)
+        if rc != 0:
+            raise _eng.EngineError("trl_resnet_trunk failed: %s" % L.trl_last_error().decode())
+        return out
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
@@ -342,16 +375,27 @@ class BaseResNet(nn.Module):
     def head_inputs(self, grids, vec):
         fd = self._folded or self.prepare()._folded
         n = vec.shape[0]
-        x = torch.relu(F.conv2d(grids.reshape(2 * n, 1, ROWS, COLS), *fd["stem"], padding=1))
-        for (w1, b1), (w2, b2) in fd["blocks"]:
-            h = torch.relu(F.conv2d(x, w1, b1, padding=1))
-            x = torch.relu(F.conv2d(h, w2, b2, padding=1) + x)
-        a_feat, o_feat = x[:n], x[n:]
         a_extra, o_extra, color = vec[:, :52], vec[:, 52:104], vec[:, 104:105]
-        o_col = torch.relu(F.conv2d(o_feat, *fd["opp"])).flatten(1)
+        hip = fd["packed_tower"] is not None and self.use_hip_trunk
+        if hip:
+            z = self._tower_hip(grids.reshape(2 * n, ROWS * COLS), fd["packed_tower"])
+            k = self.model_config.own_kernels
+            o_col = torch.relu(z[n:, k] + fd["opp"][1])
+        else:
+            x = torch.relu(F.conv2d(grids.reshape(2 * n, 1, ROWS, COLS), *fd["stem"], padding=1))
+            for (w1, b1), (w2, b2) in fd["blocks"]:
+                h = torch.relu(F.conv2d(x, w1, b1, padding=1))
+                x = torch.relu(F.conv2d(h, w2, b2, padding=1) + x)
+            a_feat, o_feat = x[:n], x[n:]
+            o_col = torch.relu(F.conv2d(o_feat, *fd["opp"])).flatten(1)
         opp_repr = torch.relu(F.linear(torch.cat([o_col, o_extra], dim=1), *fd["enc"]))
         bias_vec = F.linear(torch.cat([opp_repr, a_extra, color], dim=1), self.bias_project.weight, self.bias_project.bias)
-        flat = torch.relu(F.conv2d(a_feat + bias_vec.view(n, -1, 1, 1), *fd["own"])).flatten(1)
+        if hip:
+            # own_collapse is linear: W (a_feat + bias) + t = [W a_feat from the kernel] + W bias + t
+            wo, to = fd["own"]
+            flat = torch.relu(z[:n, :k] + (F.linear(bias_vec, wo.reshape(k, -1)) + to).unsqueeze(2)).flatten(1)
+        else:
+            flat = torch.relu(F.conv2d(a_feat + bias_vec.view(n, -1, 1, 1), *fd["own"])).flatten(1)
         hx = torch.cat([flat, a_extra, color], dim=1).contiguous()
         v = F.linear(torch.relu(F.linear(hx, *fd["v0"])), self.value_head["3"].weight, self.value_head["3"].bias).reshape(n)
         return v, hx
