@@ -200,9 +200,9 @@ __global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__res
 
 // ---- wide tower: 32 / 64 filters (BASELINE config C5: 20 blocks x 64 filters) ------------------------------------
 // Same algorithm and data layout as k_trunk16, generalised over the channel count FF (a multiple of 16):
-//   * the activations are CG = FF/16 planes of [42 x 12 padded positions][16 channels] in LDS (FF = 64: 126 KB,
-//     one board per CU; FF = 32: 63 KB, two boards per CU), so the A fragment of (tap, channel group) is the same
-//     conflict-free ds_read_b128 as in the 16-filter kernel;
+//   * the activations are FF/4 quad-planes of [42 x 12 padded positions][4 channels] in LDS (FF = 64: 126 KB, one
+//     board per CU; FF = 32: 63 KB, two boards per CU); the A fragment of (tap, 16-channel group) is one
+//     conflict-free ds_read_b128 per lane (lane (m, g) reads quad g of position m);
 //   * 2 NN waves (NN = FF/16 N-tiles): wave = ntile + NN * mq owns the 16 output channels of N-tile `ntile` for the
 //     even (mq = 0: 13) or odd (mq = 1: 12) M-tiles; FF = 64 -> 8 waves, 25 tiles per SIMD; two waves per SIMD
 //     either way (256 VGPRs each);
@@ -211,21 +211,35 @@ __global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__res
 //     (52 MFMAs per 1 KB of weights);
 //   * residual stream and accumulators stay in registers in MFMA C/D layout (2 x 52 VGPRs at FF = 64).
 // Per board at FF = 64, 20 blocks: 40 convs x 100 (M,N) tiles x 144 K-steps = 576 000 MFMAs = 1.18 GFLOP.
+#ifdef TRL_PROFILE
+__device__ unsigned long long g_tprof[8 * 8];       // [wave][phase] cycles of workgroup 0 (scripts/tower_phase_probe.py)
+#define TPROF_T(v) unsigned long long v = __builtin_readcyclecounter()
+#define TPROF_ADD(i, a, b) do { tprof[i] += (b) - (a); } while (0)
+#else
+#define TPROF_T(v)
+#define TPROF_ADD(i, a, b)
+#endif
+
 template <int FF> struct Wide {
     static constexpr int NN = FF / 16, CG = FF / 16, WAVES = 2 * NN, MSPLIT = 2, TS = (NT + MSPLIT - 1) / MSPLIT;
     static constexpr int THREADS = 64 * WAVES;
-    static constexpr int PLANE = BUF_FLOATS;
-    static constexpr int LDS_FLOATS = CG * PLANE + BW * BH;
+    // LDS layout of a 16-channel group: 4 quad-planes [42 x 12 padded positions][4 channels] (+4 floats of padding per
+    // quad-plane): the ds_read_b128 of 8 consecutive lanes (8 consecutive positions of one quad) covers 128 contiguous
+    // bytes = every bank once; with [position][16 channels] the same read is a 4-way bank conflict
+    static constexpr int QS = 4, PLANEQ = PW * PH * QS + 4, PLANE = 4 * PLANEQ;
+    static constexpr int LDS_FLOATS = CG * PLANE + BW * BH + 200;   // planes, padded input board, write-offset table
     static constexpr int CONVW = 9 * FF * FF;
     static constexpr int WBLOCKW = 3 * FF + 2 * CONVW;
 };
 
 template <int FF, int S0, int S1>
-__device__ __forceinline__ void conv_wide_group(const float *pl, const float (&w)[4], const int (&base)[Wide<FF>::TS], int off,
-                                                f32x4 (&acc)[Wide<FF>::TS]) {
-    f32x4 a[S1 - S0];
+__device__ __forceinline__ void wide_load(const float *pl, const int (&base)[Wide<FF>::TS], int off, f32x4 (&a)[S1 - S0]) {
 #pragma unroll
     for (int s = S0; s < S1; s++) a[s - S0] = *reinterpret_cast<const f32x4 *>(pl + base[s] + off);
+}
+
+template <int FF, int S0, int S1>
+__device__ __forceinline__ void wide_mfma(const f32x4 (&a)[S1 - S0], const float (&w)[4], f32x4 (&acc)[Wide<FF>::TS]) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {           // S1 - S0 independent accumulator chains per K-step
 #pragma unroll
@@ -233,15 +247,20 @@ __device__ __forceinline__ void conv_wide_group(const float *pl, const float (&w
     }
 }
 
-// acc[0 .. NTL) += conv3x3(planes)[tiles of this wave]; NTL = 13 (even tiles) or 12 (odd tiles);
-// wn = the first K-step's B operands, already in flight (loaded before the barrier that precedes the conv)
+// acc[0 .. NTL) += conv3x3(planes)[tiles of this wave]; NTL = 13 (even tiles) or 12 (odd tiles).
+// wn = the first K-step's B operands, already in flight (loaded before the barrier that precedes the conv).
+// Software pipeline over the 36 (channel group, tap) steps x 2 tile groups: the A fragments of the next group are
+// requested before the MFMAs of the current one are issued, so a wave running alone on its SIMD does not stall on LDS.
 template <int FF, int NTL>
 __device__ __forceinline__ void conv_wide(const float *lds, const float *wq, float (&wn)[4], const int (&base)[Wide<FF>::TS],
                                           int g, f32x4 (&acc)[Wide<FF>::TS]) {
     using W = Wide<FF>;
-    constexpr int WSTEP = W::NN * 64;
+    constexpr int WSTEP = W::NN * 64, H = (NTL + 1) / 2;
+    f32x4 a0[H], a1[NTL - H];
+    const float *pl = lds + g * W::PLANEQ;
+    wide_load<FF, 0, H>(pl, base, 0, a0);
     for (int cg = 0; cg < W::CG; cg++) {
-        const float *pl = lds + cg * W::PLANE + 4 * g;
+        const float *pn = lds + (cg + 1 < W::CG ? cg + 1 : cg) * W::PLANE + g * W::PLANEQ;   // (the last prefetch of a conv is unused)
 #pragma unroll
         for (int tap = 0; tap < 9; tap++) {
             float w[4];
@@ -250,11 +269,18 @@ __device__ __forceinline__ void conv_wide(const float *lds, const float *wq, flo
             wq += 4 * WSTEP;                          // next (tap, channel group); the last prefetch of a conv reads the
 #pragma unroll                                        // first words of what follows it in the packed buffer (unused)
             for (int j = 0; j < 4; j++) wn[j] = wq[j * WSTEP];
-            const int off = ((tap / 3) * PW + (tap % 3)) * STRIDE;
-            constexpr int H = (NTL + 1) / 2;
-            conv_wide_group<FF, 0, H>(pl, w, base, off, acc);
-            conv_wide_group<FF, H, NTL>(pl, w, base, off, acc);
+            const int off = ((tap / 3) * PW + (tap % 3)) * W::QS;
+            const int offn = (((tap + 1) % 9 / 3) * PW + ((tap + 1) % 9 % 3)) * W::QS;
+            wide_load<FF, H, NTL>(pl, base, off, a1);
+            __builtin_amdgcn_sched_barrier(0);        // keep the weight / A-fragment requests ahead of the MFMAs that hide them
+            wide_mfma<FF, 0, H>(a0, w, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            wide_load<FF, 0, H>(tap == 8 ? pn : pl, base, offn, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            wide_mfma<FF, H, NTL>(a1, w, acc);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        pl = pn;
     }
 }
 
@@ -273,6 +299,9 @@ __global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float
     if (need && !need[blockIdx.x]) return;
     __shared__ __attribute__((aligned(16))) float lds[W::LDS_FLOATS];
     float *brd = lds + W::CG * W::PLANE;
+    // otab[p / 4] = the plane offsets (in floats) of positions p .. p + 3, four u16: the write phases look them up
+    // instead of dividing by the board width
+    uint2 *otab = reinterpret_cast<uint2 *>(brd + BW * BH);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, co = lane & 15;
@@ -283,6 +312,12 @@ __global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float
     for (int i = tid; i < W::LDS_FLOATS; i += THREADS) lds[i] = 0.f;
     __syncthreads();
     for (int i = tid; i < 400; i += THREADS) brd[(i / 10 + 2) * BW + (i % 10) + 2] = boards[board * 400 + i];
+    for (int i = tid; i < 100; i += THREADS) {
+        unsigned o[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { int p = 4 * i + r; o[r] = ((p / 10 + 1) * PW + (p % 10) + 1) * W::QS; }
+        otab[i] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+    }
     __syncthreads();
 
     // slot s of this wave is M-tile mq + 2 s (slot 12 of the odd waves does not exist: clamped here, never computed)
@@ -291,7 +326,7 @@ __global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float
     for (int s = 0; s < TS; s++) {
         int T = mq + MSPLIT * s; if (T >= NT) T = NT - 1;
         int p = 16 * T + (lane & 15);
-        base[s] = ((p / 10) * PW + (p % 10)) * STRIDE;
+        base[s] = ((p / 10) * PW + (p % 10)) * W::QS;
     }
 
     f32x4 x[TS];
@@ -320,9 +355,13 @@ __global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float
         }
     }
 
-    float *own = lds + ntile * W::PLANE + co;          // this lane's output channel inside its plane
+    float *own = lds + ntile * W::PLANE + (co >> 2) * W::PLANEQ + (co & 3);   // this lane's output channel in its quad-plane
     const float *wb = wts + FF * STEM + (POST ? FF : 0);
     f32x4 acc[TS];
+#ifdef TRL_PROFILE
+    unsigned long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    TPROF_T(tp_begin);
     // two layers per residual block, one loop body for both (the conv code exists once per tile count)
     for (int layer = 0; layer < 2 * n_blocks; layer++) {
         const bool first = !(layer & 1);
@@ -337,6 +376,7 @@ __global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float
         }
         wq += ntile * 64 + lane;
         float wn[4];
+        TPROF_T(tp0);
 #pragma unroll
         for (int j = 0; j < 4; j++) wn[j] = wq[j * WSTEP];
         // conv input -> planes (own positions): the block input (pre-activation: through bn1 + relu) for the first
@@ -345,19 +385,23 @@ __global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float
         for (int s = 0; s < TS; s++) {
             int T = mq + MSPLIT * s;
             if (T < NT) {
+                const uint2 o = otab[4 * T + g];
+                const unsigned off[4] = {o.x & 0xffffu, o.x >> 16, o.y & 0xffffu, o.y >> 16};
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    int p = 16 * T + 4 * g + r;
                     float v = first ? (POST ? x[s][r] : fmaf(x[s][r], sc, sh)) : acc[s][r];
-                    own[((p / 10 + 1) * PW + (p % 10) + 1) * STRIDE] = fmaxf(v, 0.f);
+                    own[off[r]] = fmaxf(v, 0.f);
                 }
             }
         }
+        TPROF_T(tp1);
         __syncthreads();
+        TPROF_T(tp2);
 #pragma unroll
         for (int s = 0; s < TS; s++) acc[s] = f32x4{bias, bias, bias, bias};
         if (mq == 0) conv_wide<FF, TS>(lds, wq, wn, base, g, acc);
         else conv_wide<FF, NT - TS>(lds, wq, wn, base, g, acc);
+        TPROF_T(tp3);
         if (!first) {
 #pragma unroll
             for (int s = 0; s < TS; s++) {
@@ -366,8 +410,19 @@ __global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float
             }
             wb += POST ? 2 * FF + 2 * W::CONVW : W::WBLOCKW;
         }
+        TPROF_T(tp4);
         __syncthreads();                              // every wave has read its inputs: the planes can be overwritten
+        TPROF_T(tp5);
+        TPROF_ADD(0, tp0, tp1); TPROF_ADD(1, tp1, tp2); TPROF_ADD(2, tp2, tp3); TPROF_ADD(3, tp3, tp4); TPROF_ADD(4, tp4, tp5);
     }
+#ifdef TRL_PROFILE
+    {
+        TPROF_T(tp_end);
+        tprof[5] = tp_end - tp_begin;
+        if (blockIdx.x == 0 && lane == 0)
+            for (int i = 0; i < 8; i++) g_tprof[wave * 8 + i] = tprof[i];
+    }
+#endif
 
     float *part = lds;                                 // [kout][NN][400] partial sums (the planes are dead now)
     if (POST) {
@@ -476,5 +531,12 @@ int trl_resnet_trunk(const float *dev_boards, int n_boards, const float *dev_pac
     HIPCHK(hipGetLastError());
     return TRL_OK;
 }
+
+#ifdef TRL_PROFILE
+int trl_debug_tower_prof(unsigned long long *host_out) {
+    HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tprof), sizeof(unsigned long long) * 64));
+    return TRL_OK;
+}
+#endif
 
 }  // extern "C"
