@@ -14,10 +14,11 @@ boards = (torch.rand((2048, 1, 40, 10), device="cuda") < 0.3).float()
 for _ in range(3):
     net.trunk(boards)
 torch.cuda.synchronize()
-buf = (C.c_ulonglong * 64)()
+buf = (C.c_ulonglong * 160)()
 L.trl_debug_tower_prof(buf)
-v = np.array(buf[:], dtype=np.float64).reshape(8, 8)
+v = np.array(buf[:], dtype=np.float64).reshape(2, 8, 10)
 names = ["write planes", "barrier 1", "conv", "x update", "barrier 2", "layer loop total"]
-print("per conv (cycles, %d convs), waves 0..7:" % (2 * blocks))
-for i, nm in enumerate(names):
-    print("  %-18s" % nm, " ".join("%8.0f" % (v[w, i] / (2 * blocks)) for w in range(8)))
+for k, wg in enumerate((0, 1500)):
+    print("workgroup %d: per conv (cycles, %d convs), waves 0..7:" % (wg, 2 * blocks))
+    for i, nm in enumerate(names):
+        print("  %-18s" % nm, " ".join("%8.0f" % (v[k, w, i] / (2 * blocks)) for w in range(8)))

@@ -10,6 +10,7 @@
 //     four K-steps of one tap is ONE ds_read_b128 (the K order inside a tap is permuted so that a
 //     lane's four channels are contiguous; the weights are packed on the host in the same order);
 //   * the layer's whole B operand (144 x 16 weights) sits in 36 VGPRs per lane;
+//   * the 5x5 stem runs on the matrix cores as well (im2col, K = 25 padded to 28);
 //   * the residual stream never leaves registers (each wave owns 6-7 M-tiles in MFMA C/D layout);
 //   * eval-mode batch norms are folded on the host (nets.py prepare()): per-channel scale/shift
 //     before the first conv of a block, a bias after it;
@@ -22,6 +23,15 @@
 #include "trl_internal.h"
 
 namespace {
+
+#ifdef TRL_PROFILE
+__device__ unsigned long long g_tprof[2 * 8 * 10];  // [workgroup 0 | 1500][wave][phase] cycles (scripts/tower*_phase_probe.py)
+#define TPROF_T(v) unsigned long long v = __builtin_readcyclecounter()
+#define TPROF_ADD(i, a, b) do { tprof[i] += (b) - (a); } while (0)
+#else
+#define TPROF_T(v)
+#define TPROF_ADD(i, a, b)
+#endif
 
 constexpr int F = 16;
 constexpr int PW = 12, PH = 42;                 // padded activation plane (1-cell zero border)
@@ -88,13 +98,19 @@ __global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__res
                                                               int n_blocks, float *__restrict__ out,
                                                               const uint8_t *__restrict__ need) {
     if (need && !need[blockIdx.x]) return;      // board whose tower output is already cached (trl_mcts_zcache)
+    TPROF_T(tp_start);
+    // wave priority: what is not an MFMA loop (prologue, activation writes, reductions) runs at high priority -- it is
+    // short, and the sooner a wave is back in a conv the fuller the matrix pipe (the arbiter otherwise serves the oldest
+    // wave first, so a new workgroup's prologue crawls behind its neighbours' MFMA streams)
+    __builtin_amdgcn_s_setprio(3);
     __shared__ __attribute__((aligned(16))) float lds[BUF_FLOATS + BW * BH + 4 * 256];
     float *bufA = lds, *brd = lds + BUF_FLOATS, *part = lds + BUF_FLOATS + BW * BH;      // part: K-split partials of tile 24
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, co = lane & 15;
     const size_t board = blockIdx.x;
 
-    for (int i = tid; i < BUF_FLOATS + BW * BH + 4 * 256; i += TRUNK_THREADS) lds[i] = 0.f;
+    for (int i = tid; i < (BUF_FLOATS + BW * BH + 4 * 256) / 4; i += TRUNK_THREADS)
+        reinterpret_cast<f32x4 *>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     for (int i = tid; i < 400; i += TRUNK_THREADS) brd[(i / 10 + 2) * BW + (i % 10) + 2] = boards[board * 400 + i];
     __syncthreads();
@@ -110,29 +126,39 @@ __global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__res
         base[s] = ((p / 10) * PW + (p % 10)) * STRIDE;
     }
 
-    // conv1: 5x5, one input channel, on the vector ALU (0.9 % of the FLOPs), straight into C/D layout
+    // conv1: 5x5, one input channel, as an im2col GEMM on the matrix cores too: K = 25 taps padded to 7 K-steps of 4
+    // (A[m][k] = board value under tap 4 step + k, B[k][n] = w1[n][tap], zero for the three padding taps); the C/D
+    // layout is that of the residual stream.  (On the vector ALU this stage is 700 LDS reads + 700 FMAs per lane and,
+    // starved by the neighbours' MFMA streams, took a fifth of a workgroup's lifetime.)
     f32x4 x[7];
     {
-        float w1[25];
+        float wB[7];
+        int toff[7];
 #pragma unroll
-        for (int i = 0; i < 25; i++) w1[i] = wts[co * 25 + i];
+        for (int st = 0; st < 7; st++) {
+            const int t = 4 * st + g, tc = t < 25 ? t : 24;
+            wB[st] = t < 25 ? wts[co * 25 + tc] : 0.f;
+            toff[st] = (tc / 5) * BW + (tc % 5);
+        }
 #pragma unroll
         for (int s = 0; s < 7; s++) {
             int T = wave + 4 * s; if (T >= NT) T = NT - 1;
+            const int p = 16 * T + (lane & 15), pb = (p / 10) * BW + (p % 10);
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                int p = 16 * T + 4 * g + r, py = p / 10, px = p % 10;
-                float a = 0.f;
-#pragma unroll
-                for (int k = 0; k < 25; k++) a = fmaf(w1[k], brd[(py + k / 5) * BW + px + (k % 5)], a);
-                x[s][r] = a;
-            }
+            for (int st = 0; st < 7; st++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(brd[pb + toff[st]], wB[st], c, 0, 0, 0);
+            x[s] = c;
         }
     }
 
     const float *wb = wts + 400;
     f32x4 acc[7];
+#ifdef TRL_PROFILE
+    unsigned long long tprof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    TPROF_T(tp_begin);
     for (int b = 0; b < n_blocks; b++, wb += WBLOCK) {
+        TPROF_T(tp0);
         const float s1 = wb[co], t1 = wb[16 + co], bias_a = wb[32 + 2304 + co];
         // H1 = relu(bn1(x)) -> buffer A (own positions)
 #pragma unroll
@@ -146,10 +172,16 @@ __global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__res
                 }
             }
         }
+        TPROF_T(tp1);
         __syncthreads();
+        TPROF_T(tp2);
+        __builtin_amdgcn_s_setprio(0);
         conv3x3<true>(bufA, wb + 32, bias_a, base, wave, g, lane, acc);
+        __builtin_amdgcn_s_setprio(3);
         *reinterpret_cast<f32x4 *>(part + wave * 256 + lane * 4) = acc[6];
+        TPROF_T(tp3);
         __syncthreads();                              // every wave has read its halo: the buffer can be overwritten
+        TPROF_T(tp4);
         if (wave == 0) {
             f32x4 t = *reinterpret_cast<const f32x4 *>(part + lane * 4);
             t += *reinterpret_cast<const f32x4 *>(part + 256 + lane * 4);
@@ -168,12 +200,20 @@ __global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__res
                 }
             }
         }
+        TPROF_T(tp5);
         __syncthreads();
+        TPROF_T(tp6);
+        __builtin_amdgcn_s_setprio(0);
         conv3x3<false>(bufA, wb + 32 + 2304 + 16, 0.f, base, wave, g, lane, acc);
+        __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int s = 0; s < 6; s++) x[s] += acc[s];
         *reinterpret_cast<f32x4 *>(part + wave * 256 + lane * 4) = acc[6];
+        TPROF_T(tp7);
         __syncthreads();
+        TPROF_T(tp8);
+        TPROF_ADD(0, tp0, tp1); TPROF_ADD(1, tp1, tp2); TPROF_ADD(2, tp2, tp3); TPROF_ADD(3, tp3, tp4); TPROF_ADD(4, tp4, tp5);
+        TPROF_ADD(5, tp5, tp6); TPROF_ADD(6, tp6, tp7); TPROF_ADD(7, tp7, tp8);
         if (wave == 0) {
             f32x4 t = *reinterpret_cast<const f32x4 *>(part + lane * 4);
             t += *reinterpret_cast<const f32x4 *>(part + 256 + lane * 4);
@@ -183,6 +223,14 @@ __global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__res
         }
     }
 
+#ifdef TRL_PROFILE
+    {
+        TPROF_T(tp_end);
+        tprof[8] = tp_end - tp_begin; tprof[9] = tp_begin - tp_start;
+        if ((blockIdx.x == 0 || blockIdx.x == 1500) && lane == 0)
+            for (int i = 0; i < 10; i++) g_tprof[((blockIdx.x ? 1 : 0) * 8 + wave) * 10 + i] = tprof[i];
+    }
+#endif
     // tail: relu(bn(x)) -> 1x1 conv over the 16 channels (= 16 lanes) -> folded bn -> relu
     const float s = wb[co], t = wb[16 + co], wk = wb[32 + co], bk = wb[48];
 #pragma unroll
@@ -211,21 +259,13 @@ __global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__res
 //     (52 MFMAs per 1 KB of weights);
 //   * residual stream and accumulators stay in registers in MFMA C/D layout (2 x 52 VGPRs at FF = 64).
 // Per board at FF = 64, 20 blocks: 40 convs x 100 (M,N) tiles x 144 K-steps = 576 000 MFMAs = 1.18 GFLOP.
-#ifdef TRL_PROFILE
-__device__ unsigned long long g_tprof[8 * 8];       // [wave][phase] cycles of workgroup 0 (scripts/tower_phase_probe.py)
-#define TPROF_T(v) unsigned long long v = __builtin_readcyclecounter()
-#define TPROF_ADD(i, a, b) do { tprof[i] += (b) - (a); } while (0)
-#else
-#define TPROF_T(v)
-#define TPROF_ADD(i, a, b)
-#endif
-
 template <int FF> struct Wide {
     static constexpr int NN = FF / 16, CG = FF / 16, WAVES = 2 * NN, MSPLIT = 2, TS = (NT + MSPLIT - 1) / MSPLIT;
     static constexpr int THREADS = 64 * WAVES;
     // LDS layout of a 16-channel group: 4 quad-planes [42 x 12 padded positions][4 channels] (+4 floats of padding per
-    // quad-plane): the ds_read_b128 of 8 consecutive lanes (8 consecutive positions of one quad) covers 128 contiguous
-    // bytes = every bank once; with [position][16 channels] the same read is a 4-way bank conflict
+    // quad-plane, which spreads the C/D-layout ds_write_b32 of the 4 channel quads over the banks).  Measured: planes
+    // padded to 2048 floats (A reads conflict-free by the 4 x 16-lane ds_read_b128 bank rule) ran 1.5 % slower, and the
+    // [position][16 channels] layout of the 16-filter kernel the same as this one -- LDS is 1/3 busy, not the limit.
     static constexpr int QS = 4, PLANEQ = PW * PH * QS + 4, PLANE = 4 * PLANEQ;
     static constexpr int LDS_FLOATS = CG * PLANE + BW * BH + 200;   // planes, padded input board, write-offset table
     static constexpr int CONVW = 9 * FF * FF;
@@ -359,7 +399,7 @@ __global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float
     const float *wb = wts + FF * STEM + (POST ? FF : 0);
     f32x4 acc[TS];
 #ifdef TRL_PROFILE
-    unsigned long long tprof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     TPROF_T(tp_begin);
     // two layers per residual block, one loop body for both (the conv code exists once per tile count)
@@ -419,8 +459,8 @@ __global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float
     {
         TPROF_T(tp_end);
         tprof[5] = tp_end - tp_begin;
-        if (blockIdx.x == 0 && lane == 0)
-            for (int i = 0; i < 8; i++) g_tprof[wave * 8 + i] = tprof[i];
+        if ((blockIdx.x == 0 || blockIdx.x == 1500) && lane == 0)
+            for (int i = 0; i < 10; i++) g_tprof[((blockIdx.x ? 1 : 0) * 8 + wave) * 10 + i] = tprof[i];
     }
 #endif
 
@@ -534,7 +574,7 @@ int trl_resnet_trunk(const float *dev_boards, int n_boards, const float *dev_pac
 
 #ifdef TRL_PROFILE
 int trl_debug_tower_prof(unsigned long long *host_out) {
-    HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tprof), sizeof(unsigned long long) * 64));
+    HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tprof), sizeof(unsigned long long) * 160));
     return TRL_OK;
 }
 #endif
