@@ -124,6 +124,70 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
     }
 
 
+WIDE_FLOP_PER_BOARD = 2 * 400 * (25 * 64 + 40 * 576 * 64 + 64)      # C5 tower: conv5x5 + 40 conv3x3 (64 ch) + conv1x1 = 1.18 GFLOP
+
+
+def bench_c5(args, rank, local_rank, world, dist, dev, barrier):
+    """C5: the MFMA-bound regime -- AlphaSame(20, 64), MAX_ITER=800, forced playouts + policy-target pruning.
+    A move takes 400 or 2000 simulations (playout cap), so a bounded run completes few moves per game: the rate
+    reported is simulations/s, with moves/s = simulations/s / 800 (the mean) beside the moves actually completed."""
+    import torch
+    import tetris_rl_amd as trl
+    from tetris_rl_amd import parallel
+    n = args.mcts_games
+    torch.manual_seed(0)
+    mc = trl.AlphaSameConfig(blocks=20, filters=64)
+    net = trl.AlphaSame(mc)
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=800, training=True,
+                     use_forced_playouts_and_policy_target_pruning=True)
+    sp = trl.SelfPlay(cfg, net, n, seed=SEED, device=local_rank, streams=parallel.game_streams(rank, n),
+                      auto_reset=True, use_graph=True, record_capacity=1 << 16)
+    sp.tick(args.c5_warmup)
+    sp.drain()
+    st0 = sp.stats()
+    barrier()
+    t0 = time.perf_counter()
+    done = 0
+    while done < args.c5_ticks:
+        k = min(256, args.c5_ticks - done)
+        sp.tick(k)
+        done += k
+        sp.drain()
+    sp.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st1 = sp.stats()
+    if st1["overflow"] or st1["records_dropped"]:
+        raise SystemExit("tree / record capacity overflowed during the C5 benchmark: results invalid")
+    boards = sp.grids.reshape(2 * n, 1, 40, 10)
+    with torch.cuda.stream(sp.stream):
+        sp.net.trunk(boards)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 5
+        e0.record(sp.stream)
+        for _ in range(reps):
+            sp.net.trunk(boards)
+        e1.record(sp.stream)
+    e1.synchronize()
+    trunk_ms = e0.elapsed_time(e1) / reps
+    elapsed, moves_total = parallel.reduce_job(elapsed, st1["moves"] - st0["moves"], dist, dev)
+    _, sims_total = parallel.reduce_job(elapsed, st1["simulations"] - st0["simulations"], dist, dev)
+    tflops = WIDE_FLOP_PER_BOARD * 2 * n / (trunk_ms * 1e-3) / 1e12
+    return {
+        "metric": "MCTS simulations/sec at MAX_ITER=800 (GPU search + AlphaSame(20,64) fp32, forced playouts + pruning)",
+        "value": round(sims_total / elapsed, 1), "unit": "simulations/s",
+        "moves_per_sec_at_mean_800_sims": round(sims_total / elapsed / 800.0, 2),
+        "ms_per_tick": round(elapsed * 1e3 / args.c5_ticks, 4),
+        "config": {"workload": "C5: %d concurrent self-play games per GPU, MAX_ITER=800, training=True (playout cap "
+                               "2000/400), forced playouts + policy-target pruning, AlphaSame blocks=20 filters=64 random init"
+                               % n, "games_per_gpu": n, "ticks_timed": args.c5_ticks, "moves_completed": moves_total,
+                   "simulations_timed": sims_total},
+        "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "kernel": "k_trunk_wide<64>",
+                     "kernel_ms": round(trunk_ms, 4), "flop_per_board": WIDE_FLOP_PER_BOARD, "boards_per_launch": 2 * n},
+    }
+
+
 def cpu_baseline_mcts(seconds_target=12.0):
     """oracle search (C) + the stub evaluator is not the C3 workload; the honest CPU statement of C3 is
     the oracle's play_game with the same net on PyTorch-CPU.  One game slot, one thread, bounded sample."""
@@ -190,6 +254,9 @@ def main():
     ap.add_argument("--mcts-games", type=int, default=1024, help="concurrent self-play games per GPU (C3: 1024)")
     ap.add_argument("--mcts-ticks", type=int, default=3200, help="timed search ticks (3200 = 20 moves/game at 160 sims)")
     ap.add_argument("--mcts-warmup", type=int, default=200)
+    ap.add_argument("--no-c5", action="store_true", help="skip the C5 (20x64 net, MAX_ITER=800) measurement")
+    ap.add_argument("--c5-ticks", type=int, default=1200, help="timed search ticks of the C5 measurement")
+    ap.add_argument("--c5-warmup", type=int, default=50)
     args = ap.parse_args()
 
     import numpy as np
@@ -250,6 +317,7 @@ def main():
     kernel_ms, _ = parallel.reduce_job(kernel_ms, 0, dist, dev)
     eng.close()
     mcts = None if args.no_mcts else bench_mcts(args, rank, local_rank, world, dist, dev, barrier)
+    c5 = None if (args.no_mcts or args.no_c5) else bench_c5(args, rank, local_rank, world, dist, dev, barrier)
 
     if rank == 0:
         value = steps_total / elapsed
@@ -284,6 +352,8 @@ def main():
         }
         if mcts is not None:
             out["mcts"] = mcts
+        if c5 is not None:
+            out["mcts_c5"] = c5
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             if mcts is not None:

@@ -305,6 +305,15 @@ int  trl_mcts_leaf_states(trl_engine *h, trl_game_state *host_out, int32_t *host
 /* root children of every slot's current tree: counts[n], moves / visits [n][TRL_MAX_LEGAL], q / p as fp64 */
 int  trl_mcts_root_children(trl_engine *h, int32_t *counts, uint16_t *moves, int32_t *visits, double *q, double *p);
 
+/* ==== HIP graph of a search tick ==================================================================
+ * Everything issued on the engine's stream between trl_graph_begin and trl_graph_end (trl_mcts_select*,
+ * the tower, trl_mcts_expand* -- device pointers only, no host copies) is captured into one hipGraph;
+ * trl_graph_launch replays it n_times on the same stream.  Replaces the reference's Python loop over
+ * MAX_ITER iterations (ai.py:330-338) as the unit of host work.                                      */
+int  trl_graph_begin(trl_engine *h);
+int  trl_graph_end(trl_engine *h);
+int  trl_graph_launch(trl_engine *h, int n_times);
+
 /* ==== net: residual tower of AlphaSame on the device (architectures.py:27-57, 119-127) ===========
  * process_grid for filters = 16, kernels = 1: conv5x5 -> n_blocks residual blocks -> BN, ReLU ->
  * conv1x1 -> BN, ReLU -> flatten, one workgroup per board, fp32 MFMA, activations resident in LDS.

@@ -153,6 +153,8 @@ void trl_engine_destroy(trl_engine *h) {
     hipSetDevice(h->cfg.device);
     hipStreamSynchronize(h->stream);
     trl_mcts_free_internal(h);
+    if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) hipGraphDestroy(h->graph);
     hipFree(h->d_states); hipFree(h->d_counts); hipFree(h->d_moves); hipFree(h->d_in_moves); hipFree(h->d_steps);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -165,6 +167,32 @@ int trl_set_stream(trl_engine *h, void *hip_stream) {
     if (h->own_stream) { HIPCHK(hipStreamDestroy(h->stream)); h->own_stream = false; }
     if (hip_stream) h->stream = (hipStream_t)hip_stream;
     else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    return TRL_OK;
+}
+
+// ---- HIP graph of the calls issued on the engine's stream between _begin and _end ---------------------------------
+// (the search tick is three or four launch-bound kernels: replaying it as one graph removes the per-launch host cost)
+int trl_graph_begin(trl_engine *h) {
+    if (!h) return fail(TRL_E_INVALID, "%s", "null engine");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->graph_exec) { HIPCHK(hipGraphExecDestroy(h->graph_exec)); h->graph_exec = nullptr; }
+    if (h->graph) { HIPCHK(hipGraphDestroy(h->graph)); h->graph = nullptr; }
+    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    return TRL_OK;
+}
+
+int trl_graph_end(trl_engine *h) {
+    if (!h) return fail(TRL_E_INVALID, "%s", "null engine");
+    HIPCHK(hipStreamEndCapture(h->stream, &h->graph));
+    HIPCHK(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+    return TRL_OK;
+}
+
+int trl_graph_launch(trl_engine *h, int n_times) {
+    if (!h || !h->graph_exec) return fail(TRL_E_STATE, "%s", "trl_graph_launch without a captured graph");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    for (int i = 0; i < n_times; i++) HIPCHK(hipGraphLaunch(h->graph_exec, h->stream));
     return TRL_OK;
 }
 

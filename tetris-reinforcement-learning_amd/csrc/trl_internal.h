@@ -87,6 +87,8 @@ struct trl_engine {
     bool have_reset;
     float last_ms;
     trl_mcts *mcts;
+    hipGraph_t graph = nullptr;            // captured search tick (trl_graph_begin / _end / _launch)
+    hipGraphExec_t graph_exec = nullptr;
 };
 
 extern thread_local char trl_g_err[512];

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "trl_env_legal_moves", "trl_env_legal_dev", "trl_env_step", "trl_env_step_dev",
     "trl_env_rollout_random", "trl_last_kernel_ms",
     "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_expand_head", "trl_mcts_drain_records", "trl_mcts_get_stats",
-    "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16", "trl_alphasame_trunk16_need", "trl_alphasame_trunk", "trl_resnet_trunk",
+    "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16", "trl_alphasame_trunk16_need", "trl_alphasame_trunk", "trl_resnet_trunk", "trl_graph_begin", "trl_graph_end", "trl_graph_launch",
     "trl_mcts_select_need", "trl_mcts_zcache", "trl_mcts_expand_alphasame",
 ]
 
@@ -127,6 +127,9 @@ def load_library(path=None):
     L.trl_mcts_root_children.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     L.trl_mcts_select_need.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.trl_mcts_zcache.argtypes = [C.c_void_p, C.c_void_p]
+    L.trl_graph_begin.argtypes = [C.c_void_p]
+    L.trl_graph_end.argtypes = [C.c_void_p]
+    L.trl_graph_launch.argtypes = [C.c_void_p, C.c_int]
     L.trl_mcts_expand_alphasame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(TrlAlphaSameHeads)]
     L.trl_alphasame_trunk16_need.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.trl_alphasame_trunk16.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
@@ -245,6 +248,15 @@ class Engine:
 
     def mcts_select_need(self, grids_ptr, vec_ptr, need_ptr):
         _check(self._L, self._L.trl_mcts_select_need(self._h, grids_ptr, vec_ptr, need_ptr), "trl_mcts_select_need")
+
+    def graph_begin(self):
+        _check(self._L, self._L.trl_graph_begin(self._h), "trl_graph_begin")
+
+    def graph_end(self):
+        _check(self._L, self._L.trl_graph_end(self._h), "trl_graph_end")
+
+    def graph_launch(self, n=1):
+        _check(self._L, self._L.trl_graph_launch(self._h, int(n)), "trl_graph_launch")
 
     def mcts_zcache(self, z_ptr):
         _check(self._L, self._L.trl_mcts_zcache(self._h, z_ptr), "trl_mcts_zcache")

@@ -160,14 +160,17 @@ class AlphaSame(nn.Module):
         wk, bk = fd["k1"]
         return torch.relu(F.conv2d(torch.relu(x * s + t), wk, bk)).flatten(1)
 
-    def _trunk_hip(self, boards, packed, need=None):
+    def _trunk_hip(self, boards, packed, need=None, out=None):
         """fused HIP tower (csrc/trl_net.hip) on the current stream; raises if the library is missing.
-        need: optional uint8 [m] -- boards with 0 are skipped (their output rows stay zero)"""
+        need: optional uint8 [m] -- boards with 0 are skipped (their output rows stay zero, or, with a caller's
+        `out` buffer, untouched)"""
         from . import engine as _eng
         L = _eng.load_library()
         m = boards.shape[0]
         x = boards.reshape(m, ROWS * COLS).contiguous()
-        if need is None:
+        if out is not None:
+            pass
+        elif need is None:
             out = torch.empty((m, ROWS * COLS), dtype=torch.float32, device=boards.device)
         else:
             out = torch.zeros((m, ROWS * COLS), dtype=torch.float32, device=boards.device)
@@ -199,10 +202,11 @@ class AlphaSame(nn.Module):
                                       ph.weight.data_ptr(), ph.bias.data_ptr(), b3, int(bool(self.use_tanh)))
 
     @torch.no_grad()
-    def tower_need(self, grids, need):
-        """tower outputs [2n, 400] of the boards flagged in need (uint8 [2n]); the others are zero"""
+    def tower_need(self, grids, need, out=None):
+        """tower outputs [2n, 400] of the boards flagged in need (uint8 [2n]); the others are zero (left as they
+        are in a caller-provided `out`)"""
         fd = self._folded or self.prepare()._folded
-        return self._trunk_hip(grids.reshape(-1, 1, ROWS, COLS), fd["packed_tower"], need)
+        return self._trunk_hip(grids.reshape(-1, 1, ROWS, COLS), fd["packed_tower"], need, out)
 
     @torch.no_grad()
     def head_inputs(self, grids, vec, z=None):

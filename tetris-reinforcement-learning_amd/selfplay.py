@@ -138,8 +138,12 @@ class SelfPlay:
         self.tower_cache = self.tower_cache and policy_head == "legal" and getattr(self.net, "supports_tower_cache", False)
         # every head of AlphaSame inside the expand kernel (trl_mcts_expand_alphasame): the tick is three HIP kernels
         self.heads = self.net.device_heads() if (self.tower_cache and device_heads and hasattr(self.net, "device_heads")) else None
+        if self.heads is not None:
+            with torch.cuda.stream(self.stream):
+                self.z = torch.zeros((2 * self.n, _eng.GRID_FLOATS), dtype=torch.float32, device=self.device)
         self.stream.synchronize()
         self.graph = None
+        self.native_graph = False
         self.ticks = 0
         if use_graph:
             self._capture()
@@ -149,10 +153,13 @@ class SelfPlay:
         # v / p / x / z live in the stream-ordered allocator (a fixed address inside a captured graph)
         if self.tower_cache:
             e.mcts_select_need(self.grids.data_ptr(), self.vec.data_ptr(), self.need.data_ptr())
-            z = self.net.tower_need(self.grids, self.need)
             if self.heads is not None:
-                e.mcts_expand_alphasame(z.data_ptr(), self.vec.data_ptr(), self.heads)
+                # all-native tick (three kernels of the library, no PyTorch op): select -> tower -> expand;
+                # the rows of self.z that the tower skips are never read (the expand kernel takes them from its cache)
+                self.net.tower_need(self.grids, self.need, out=self.z)
+                e.mcts_expand_alphasame(self.z.data_ptr(), self.vec.data_ptr(), self.heads)
                 return
+            z = self.net.tower_need(self.grids, self.need)
             e.mcts_zcache(z.data_ptr())
             v, x = self.net.evaluate_head_inputs(self.grids, self.vec, z)
             ph = self.net.policy_head
@@ -169,6 +176,15 @@ class SelfPlay:
 
     def _capture(self):
         torch = self.torch
+        if self.tower_cache and self.heads is not None:
+            # the tick is library kernels only: capture it with the library's own HIP graph (trl_graph_*); a
+            # torch.cuda.CUDAGraph replay adds half a dozen small generator-state kernels of its own per replay
+            with torch.cuda.stream(self.stream):
+                self.engine.graph_begin()
+                self._tick_body()
+                self.engine.graph_end()
+            self.native_graph = True
+            return
         with torch.cuda.stream(self.stream):
             # one eager evaluation outside the capture warms up MIOpen / rocBLAS handles and workspaces
             self.net.evaluate_packed(self.grids, self.vec)
@@ -180,6 +196,10 @@ class SelfPlay:
 
     def tick(self, n=1):
         torch = self.torch
+        if self.native_graph:
+            self.engine.graph_launch(n)
+            self.ticks += n
+            return
         with torch.cuda.stream(self.stream):           # graph replays launch on the current stream
             for _ in range(n):
                 if self.graph is not None:
