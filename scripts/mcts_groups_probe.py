@@ -8,8 +8,7 @@ from tetris_rl_amd import parallel
 torch.manual_seed(0)
 net = trl.AlphaSame(trl.AlphaSameConfig(blocks=10, filters=16))
 cfg = trl.Config(visual=False, model='pytorch', model_config=trl.AlphaSameConfig(blocks=10, filters=16), MAX_ITER=160, training=True)
-total = 1024
-for groups in (1, 2, 4):
+for total, groups in ((1024, 1), (1024, 2), (2048, 1), (2048, 2), (3072, 3), (4096, 4)):
     n = total // groups
     sps = [trl.SelfPlay(cfg, net, n, seed=20260630, streams=parallel.game_streams(g, n), use_graph=True, record_capacity=65536) for g in range(groups)]
     for sp in sps: sp.tick(20)

@@ -81,6 +81,9 @@ def test_make_training_set_is_wellformed_and_deterministic(tmp_path, monkeypatch
     assert os.path.isfile(tmp_path / "Storage" / "logs" / "stats.jsonl")
     data = json.load(open(os.path.join(cfg.data_dir, "0.txt")))
     assert isinstance(data, list) and len(data[0]) == 13
+    # the file comes from the text writer (records built as JSON text): same bytes as json.dumps of the list path
+    same = trl.make_training_set(cfg, net, 2, save_game=False, save_stats=False, seed=3)
+    assert open(os.path.join(cfg.data_dir, "0.txt")).read() == json.dumps(same)
 
 
 def test_graph_and_eager_ticks_agree():

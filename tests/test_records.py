@@ -39,6 +39,46 @@ def test_records_match_reference_play_game(golden_dir):
             assert float(rec[11]) == d["rec_z"][r_off[gi] + i]
 
 
+def test_text_writer_is_byte_identical_to_json_dumps(golden_dir):
+    """records.record_texts_for_move / finish_game_texts (templates patched in place, no Python lists) produce
+    exactly json.dumps of the list path, and hence the reference's records (sha256 fixtures)"""
+    d = np.load(os.path.join(golden_dir, "selfplay.npz"))
+    p_off = np.concatenate([[0], np.cumsum(d["game_plies"])])
+    c_off = np.concatenate([[0], np.cumsum(d["ply_child_counts"])])
+    r_off = np.concatenate([[0], np.cumsum(d["game_records"])])
+    for gi in range(d["game_ruleset"].shape[0]):
+        training = bool(d["game_training"][gi])
+        lists, texts = [[], []], [[], []]
+        for k in range(p_off[gi], p_off[gi + 1]):
+            if d["ply_save"][k] or not training:
+                st = d["ply_state"][k]
+                mv, vis = d["ply_child_moves"][c_off[k]:c_off[k + 1]], d["ply_child_visits"][c_off[k]:c_off[k + 1]]
+                lists[int(st[312])] += records.records_for_move(st, mv, vis, augment=True)
+                texts[int(st[312])] += records.record_texts_for_move(st, mv, vis, augment=True)
+        for winner in (0, -1):
+            a = records.finish_game([[list(r) for r in lists[0]], [list(r) for r in lists[1]]], winner)
+            b = records.finish_game_texts(texts, winner)
+            assert len(a) == len(b) == d["game_records"][gi]
+            for ra, tb in zip(a, b):
+                assert json.dumps(ra).encode() == tb
+        # and against the reference's hashes (winner as played: z is part of the record)
+        want = d["rec_hash"][r_off[gi]:r_off[gi + 1]]
+        z = d["rec_z"][r_off[gi]:r_off[gi + 1]]
+        winner = -1 if z[0] == 0.5 else (0 if (z[0] == 1) == (len(lists[0]) > 0) else 1)
+        got = records.finish_game_texts(texts, winner)
+        for i, tb in enumerate(got):
+            h = hashlib.sha256(json.dumps(json.loads(tb), separators=(",", ":")).encode()).hexdigest()
+            assert h == str(want[i]), "record %d of game %d" % (i, gi)
+    # not augmented, and a visit share that rounds to 0.0 (kept as a float zero; dropped by the mirror)
+    st = d["ply_state"][0]
+    mv = d["ply_child_moves"][c_off[0]:c_off[1]]
+    vis = np.ones(len(mv), dtype=np.int64); vis[0] = 60000
+    for aug in (False, True):
+        a = records.finish_game([records.records_for_move(st, mv, vis, augment=aug), []], 1, 0, 0.5, 1)
+        b = records.finish_game_texts([records.record_texts_for_move(st, mv, vis, augment=aug), []], 1, 0, 0.5, 1)
+        assert [json.dumps(r).encode() for r in a] == b
+
+
 def test_double_reflection_is_identity(golden_dir):
     """the property the reference's own test_reflections checks (tests.py:61-77)"""
     d = np.load(os.path.join(golden_dir, "selfplay.npz"))

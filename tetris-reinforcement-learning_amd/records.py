@@ -168,3 +168,139 @@ def finish_game(game_data, winner, value_min=0, value_mid=0.5, value_max=1):
         for rec in game_data[player]:
             rec.insert(-1, z)
     return game_data[0] + game_data[1]
+
+
+# ---- fast path: the same records as JSON text, without building Python lists --------------------
+# A record of the reference's layout is ~12 400 numbers, almost all of them zeros of the policy target; building it
+# as nested lists and running json.dumps over them costs ~1 ms per record on the host -- six times the device time
+# of the search that produced it.  The writer below patches precomputed text templates instead (same bytes as
+# json.dumps of records_for_move(...) + z, pinned by tests/test_records.py against the reference's sha256 fixtures).
+class _TextTemplates:
+    def __init__(self):
+        import json
+
+        def template(arr):
+            """text of json.dumps(arr.tolist()) as a uint8 array + the offset of every element's first character"""
+            txt = json.dumps(arr.tolist()).encode()
+            buf = np.frombuffer(txt, dtype=np.uint8)
+            is_num = (buf == ord("0"))
+            starts = np.nonzero(is_num & ~np.concatenate([[False], (buf[:-1] == ord(".")) | (buf[:-1] == ord("0"))]))[0]
+            assert starts.size == arr.size
+            return txt, buf, starts
+
+        self.grid_txt, self.grid_buf, self.grid_pos = template(np.zeros((ROWS, COLS), dtype=np.float32))
+        self.pf_txt, self.pf_buf, self.pf_pos = template(np.zeros((2 + PREVIEWS, len(MINOS)), dtype=np.float32))
+        self.pi_txt_i, self.pi_buf_i, self.pi_pos_i = template(np.zeros((2 + PREVIEWS, len(MINOS)), dtype=int))
+        self.pol_txt, _, self.pol_pos = template(np.zeros(POLICY_SHAPE, dtype=int))
+        # flat policy index -> flat index of its mirror image (reflect_policy), -1 where the image leaves the table
+        n_plane, n_row, n_col = POLICY_SHAPE
+        letter_mirror = {"Z": "S", "S": "Z", "L": "J", "J": "L"}
+        self.mirror = np.full(n_plane * n_row * n_col, -1, dtype=np.int64)
+        for plane in range(n_plane):
+            piece, rotation, tspin = _PLANE_PIECE[plane]
+            size = _BOX[piece]
+            new_piece = letter_mirror.get(piece, piece)
+            new_rot = {1: 3, 3: 1}.get(rotation, rotation)
+            adjust = 0
+            if new_piece in ("Z", "S", "I") and new_rot == 3:
+                adjust, new_rot = -1, 1
+            new_plane = _plane_of(new_piece, new_rot, tspin)
+            for col in range(n_col):
+                new_col = (10 - (col - 2) - size) + 2 + adjust
+                if 0 <= new_col < n_col:
+                    for row in range(n_row):
+                        self.mirror[(plane * n_row + row) * n_col + col] = (new_plane * n_row + row) * n_col + new_col
+
+
+_templates = None
+
+
+def _tt():
+    global _templates
+    if _templates is None:
+        _templates = _TextTemplates()
+    return _templates
+
+
+def _grid_text(rows, mirrored):
+    t = _tt()
+    bits = (np.asarray(rows, dtype=np.uint32)[:, None] >> np.arange(COLS, dtype=np.uint32)) & 1
+    if mirrored:
+        bits = bits[:, ::-1]
+    buf = t.grid_buf.copy()
+    buf[t.grid_pos[bits.reshape(-1).astype(bool)]] = ord("1")
+    return buf.tobytes()
+
+
+def _pieces_text(player, mirrored):
+    t = _tt()
+    idx = [player["piece"], player["held"]] + list(player["queue"][:PREVIEWS])
+    idx += [NO_PIECE] * (2 + PREVIEWS - len(idx))
+    buf = (t.pi_buf_i if mirrored else t.pf_buf).copy()
+    pos = t.pi_pos_i if mirrored else t.pf_pos
+    for i, p in enumerate(idx):
+        if p != NO_PIECE:
+            buf[pos[i * len(MINOS) + (_PIECE_MIRROR.get(p, p) if mirrored else p)]] = ord("1")
+    return buf.tobytes()
+
+
+def _policy_text(cells):
+    """cells: {flat index: float} -> text of the [27][39][11] table with int zeros elsewhere"""
+    t = _tt()
+    out, prev = [], 0
+    for k in sorted(cells):
+        p = int(t.pol_pos[k])
+        out.append(t.pol_txt[prev:p])
+        out.append(repr(cells[k]).encode())
+        prev = p + 1
+    out.append(t.pol_txt[prev:])
+    return b"".join(out)
+
+
+def record_texts_for_move(state, child_moves, child_visits, augment=True):
+    """records_for_move as JSON text: a list of (head, tail) byte strings, the record being
+    b"[" + head + b", " + json(z) + b", " + tail + b"]" once the game's outcome is known."""
+    t = _tt()
+    s = unpack_state(state)
+    a, o = s["players"][s["turn"]], s["players"][1 - s["turn"]]
+    total = int(sum(int(v) for v in child_visits))
+    assert total != 0
+    n_row, n_col = POLICY_SHAPE[1], POLICY_SHAPE[2]
+    cells = {}
+    for m, n in zip(child_moves, child_visits):
+        n = int(n)
+        if n != 0:
+            m = int(m)
+            cells[(((m >> 10) & 31) * n_row + ((m >> 4) & 63)) * n_col + (m & 15)] = round(n / total, 4)
+    pi = _policy_text(cells)
+
+    def scalars(p):
+        return b"%d, %d, %d" % (p["b2b"], p["combo"], len(p["garbage"]))
+
+    def head(ma, mo):
+        return b", ".join([_grid_text(a["rows"], ma), _pieces_text(a, ma), scalars(a),
+                           _grid_text(o["rows"], mo), _pieces_text(o, mo), scalars(o), b"%d" % s["turn"]])
+
+    if not augment:
+        return [(head(False, False), pi)]
+    mirrored = {}
+    for k in sorted(cells):                      # reflect_policy visits (plane, col, row); a later writer would win,
+        if cells[k] > 0:                         # but the mirror is injective, so the order does not matter
+            mk = int(t.mirror[k])
+            if mk < 0:
+                raise IndexError("mirror image of a policy cell leaves the table")
+            mirrored[mk] = cells[k]
+    rpi = _policy_text(mirrored)
+    return [(head(bool(active), bool(other)), pi if active == 0 else rpi) for active in range(2) for other in range(2)]
+
+
+def finish_game_texts(game_texts, winner, value_min=0, value_mid=0.5, value_max=1):
+    """finish_game for record_texts_for_move output -> list of complete record texts (bytes)"""
+    import json
+    out = []
+    for player in range(2):
+        z = value_mid if winner == -1 else (value_max if winner == player else value_min)
+        zt = json.dumps(z).encode()
+        for h, tl in game_texts[player]:
+            out.append(b"[" + h + b", " + zt + b", " + tl + b"]")
+    return out
