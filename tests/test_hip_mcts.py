@@ -175,3 +175,73 @@ def test_many_slots_match_oracle():
         assert np.array_equal(mine["chosen"], o["ply_move"])
         assert int(end[0]["winner"]) == o["winner"]
         assert np.array_equal(end[0]["state"][:288], o["final"][:288])
+
+
+def _run_ticks(n, seed, cfg, ticks, streams=None):
+    eng = trl.Engine(n, ruleset="s2", seed=seed)
+    eng.reset(streams)
+    s = StubSearch(eng, cfg)
+    out = []
+    for t in range(ticks):
+        s.tick()
+        if t % 128 == 127 or t == ticks - 1:
+            out.append(eng.mcts_drain_records())
+    st = eng.mcts_stats()
+    eng.close()
+    r = np.concatenate(out)
+    return r[np.lexsort((r["kind"], r["ply"], r["slot"]))], st
+
+
+def test_c3_full_size_properties():
+    """BASELINE config C3 at full size -- 1024 concurrent games, MAX_ITER=160, training=True (playout cap 400/80,
+    root noise, temperature) -- with the deterministic stub evaluator, through size-independent properties:
+    determinism, slot independence (a 256-slot engine on streams 512..767 replays those slots exactly), the
+    per-record invariants of a search, and the oracle's play_game on a sample of the games."""
+    n, seed, ticks = 1024, 777, 1500
+    cfgk = dict(max_iter=160, training=1)
+    a, st = _run_ticks(n, seed, trl.mcts_config(auto_reset=0, **cfgk), ticks)
+    assert st["overflow"] == 0 and st["records_dropped"] == 0 and st["simulations"] == n * ticks
+    moves = a[a["kind"] == trl.REC_MOVE]
+    assert len(moves) > 6 * n                                   # several moves per game were searched
+    b, _ = _run_ticks(n, seed, trl.mcts_config(auto_reset=0, **cfgk), ticks)
+    assert a.tobytes() == b.tobytes()                           # deterministic
+    c, _ = _run_ticks(256, seed, trl.mcts_config(auto_reset=0, **cfgk), ticks, streams=np.arange(512, 768, dtype=np.uint32))
+    sub = a[(a["slot"] >= 512) & (a["slot"] < 768)].copy()
+    sub["slot"] -= 512
+    assert sub.tobytes() == c.tobytes()                         # a slot's games depend on (seed, stream) only
+    # search invariants (ai.py:299-659): visits of the root children sum to simulations - 1 of a 400- or 80-
+    # simulation search; the chosen move is a child; plies count up by one per slot
+    nch = moves["n_children"].astype(np.int64)
+    vis = np.array([int(m["visits"][:k].sum()) for m, k in zip(moves, nch)])
+    assert set(np.unique(vis)) <= {399, 79}
+    assert all(m["chosen"] in m["moves"][:k] for m, k in zip(moves[::37], nch[::37]))
+    assert (moves["saved"] == (vis == 399)).all()               # only the full searches are saved (ai.py:1613)
+    for g in range(0, n, 128):
+        mine = moves[moves["slot"] == g]
+        assert np.array_equal(mine["ply"], np.arange(len(mine)))
+        o = op.play_game_stub(2, seed, g, op.default_mcts_config(**cfgk))
+        k = min(len(mine), o["plies"])
+        assert k >= 5 and np.array_equal(mine["chosen"][:k], o["ply_move"][:k])
+        assert np.array_equal(mine["state"][:k], o["ply_state"][:k])
+
+
+def test_c5_search_shape_matches_oracle():
+    """BASELINE config C5's search shape -- MAX_ITER=800 (playout cap 2000/400), forced playouts + policy-target
+    pruning -- on 128 slots with the stub evaluator: the first moves of sampled games equal the oracle's, the
+    pruned visit vectors included."""
+    n, seed, ticks = 128, 31337, 3000
+    cfgk = dict(max_iter=800, training=1, use_forced=1)
+    a, st = _run_ticks(n, seed, trl.mcts_config(auto_reset=0, **cfgk), ticks)
+    assert st["overflow"] == 0 and st["records_dropped"] == 0
+    moves = a[a["kind"] == trl.REC_MOVE]
+    for g in (0, 77):
+        mine = moves[moves["slot"] == g]
+        o = op.play_game_stub(2, seed, g, op.default_mcts_config(**cfgk))
+        k = min(len(mine), o["plies"])
+        assert k >= 2 and np.array_equal(mine["chosen"][:k], o["ply_move"][:k])
+        off = np.concatenate([[0], np.cumsum(o["ply_nchild"])])
+        for i in range(k):
+            nc = int(mine["n_children"][i])
+            assert nc == o["ply_nchild"][i]
+            assert np.array_equal(mine["moves"][i][:nc], o["child_moves"][off[i]:off[i + 1]])
+            assert np.array_equal(mine["visits"][i][:nc], o["child_visits"][off[i]:off[i + 1]])
