@@ -81,12 +81,17 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
     barrier()
     t0 = time.perf_counter()
     done = 0
+    drained = []
     while done < args.mcts_ticks:
         k = min(512, args.mcts_ticks - done)
         sp.tick(k)
         done += k
-        sp.drain()                                     # records leave the device inside the timed region
+        drained.append(sp.drain().copy())              # records leave the device inside the timed region
     sp.synchronize()
+    # C4: the one exchange step of the path -- every rank's packed (state, pi, z) move records to rank 0 over RCCL
+    mine = np.concatenate(drained) if drained else np.zeros(0, dtype=trl.RECORD_DTYPE)
+    parts = parallel.gather_bytes(mine.view(np.uint8).reshape(-1), dist, dev)
+    gathered = sum(p.size for p in parts) if parts is not None else 0
     barrier()
     elapsed = time.perf_counter() - t0
     st1 = sp.stats()
@@ -117,7 +122,9 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
         "config": {"workload": "C3: %d concurrent self-play games per GPU, MAX_ITER=160, training=True "
                                "(playout cap 400/80, root noise, temperature), AlphaSame blocks=10 filters=16 random init"
                                % n, "games_per_gpu": n, "ticks_timed": args.mcts_ticks, "moves_timed": moves_total,
-                   "simulations_timed": sims_total},
+                   "simulations_timed": sims_total,
+                   "records_to_rank0_mb": round(gathered / 1e6, 1),
+                   "parallelism": "games sharded by rank; move records gathered to rank 0 (RCCL all_gather) in the timed region"},
         "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "kernel": "k_trunk16",
                      "kernel_ms": round(trunk_ms, 4), "flop_per_board": TRUNK_FLOP_PER_BOARD, "boards_per_launch": 2 * n},
