@@ -122,6 +122,15 @@ __device__ __forceinline__ void copy_state(trl_game_state *dst, const trl_game_s
     if (tid < STATE_DW) d[tid] = s[tid];
 }
 
+#ifdef TRL_PROFILE
+__device__ unsigned long long g_mprof[16];     // [0..4] k_select phases, [8..12] k_expand phases, cycles summed over slots
+#define MPROF_T(v) unsigned long long v = __builtin_readcyclecounter()
+#define MPROF_ADD(i, a, b) do { if (threadIdx.x == 0) atomicAdd(&g_mprof[i], (unsigned long long)((b) - (a))); } while (0)
+#else
+#define MPROF_T(v)
+#define MPROF_ADD(i, a, b)
+#endif
+
 // ---- tick part A --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *real, float *grids, float *vec, uint8_t *need) {
     __shared__ SelectShared sh;
@@ -129,6 +138,7 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
     const size_t nb = (size_t)slot * M.max_nodes;
     trl_game_state *pool = M.pool + (size_t)slot * M.cap_states;
     const trl_mcts_config &cfg = M.cfg;
+    MPROF_T(ms0);
     if (tid == 0) sh.ctl = M.ctl[slot];
     __syncthreads();
     if (sh.ctl.phase == 2) {                       // idle slot: feed zeros to the net
@@ -165,6 +175,7 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
     }
 
     // SELECT (ai.py:346-393): walk down by arg-max of Q + U, ties to the last child
+    MPROF_T(ms1); MPROF_ADD(0, ms0, ms1);
     int node = 0;
     while (true) {
         int n = M.t.nchild[nb + node];
@@ -215,6 +226,7 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
     }
 
     // STEP (ai.py:398-403): node.game = parent.game.copy(); make_move(move, add_bag=False)
+    MPROF_T(ms2); MPROF_ADD(1, ms1, ms2);
     int sidx, pstate = -1;
     if (node != 0) {
         const int par = M.t.parent[nb + node];
@@ -242,6 +254,7 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
     }
 
     // leaf kind + legal moves (ai.py:406-417, 472-479)
+    MPROF_T(ms3); MPROF_ADD(2, ms2, ms3);
     const trl_game_state &g = sh.b.g;
     int kind, nlegal = 0;
     if (is_terminal(g)) kind = 2;
@@ -253,6 +266,7 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
     }
 
     // game_to_X (ai.py:1364-1413): side to move first
+    MPROF_T(ms4); MPROF_ADD(3, ms3, ms4);
     {
         const trl_player_state &a = g.p[g.turn], &o = g.p[1 - g.turn];
         for (int i = tid; i < 2 * TRL_GRID_FLOATS; i += BLOCK) {
@@ -297,6 +311,7 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
         M.ctl[slot] = c;
         atomicAdd(&M.counters[0], 1ull);
     }
+    MPROF_T(ms5); MPROF_ADD(4, ms4, ms5);
 }
 
 // ---- tick part B --------------------------------------------------------------------------------------
@@ -327,6 +342,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
     const size_t nb = (size_t)slot * M.max_nodes;
     trl_game_state *pool = M.pool + (size_t)slot * M.cap_states;
     const trl_mcts_config &cfg = M.cfg;
+    MPROF_T(me0);
     if (tid == 0) sh.ctl = M.ctl[slot];
     __syncthreads();
     if (sh.ctl.phase != 1) return;
@@ -400,6 +416,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
     double value = (kind == 2) ? sh.ctl.terminal_value : (MODE == 2 ? (double)sh.hv[16] : (double)values[slot]);
 
     // EXPAND (ai.py:411-458)
+    MPROF_T(me1); MPROF_ADD(8, me0, me1);
     if (kind == 0) {
         int n = sh.ctl.leaf_nlegal;
         const int first = sh.ctl.n_nodes;
@@ -512,6 +529,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
     }
 
     // NOISE (ai.py:482-499): un-normalised gamma draws on the root's children
+    MPROF_T(me2); MPROF_ADD(9, me1, me2);
     if (cfg.training && !sh.ctl.fast && cfg.use_dirichlet && leaf == 0) {
         const int n = M.t.nchild[nb], first = M.t.first[nb];
         if (n > 0) {
@@ -531,6 +549,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
     }
 
     // BACKUP (ai.py:504-533) and FPU refresh of the unvisited siblings (ai.py:536-565)
+    MPROF_T(me3); MPROF_ADD(10, me2, me3);
     if (tid == 0) {
         value = 1.0 - value;
         const double pos = value, neg = 1.0 - value;
@@ -569,6 +588,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
     __syncthreads();
 
     // end of the search: choose, record, play (ai.py:568-614, 1610-1695)
+    MPROF_T(me4); MPROF_ADD(11, me3, me4);
     if (sh.ctl.iter >= sh.ctl.max_iter) {
         const int n = M.t.nchild[nb], first = M.t.first[nb];
         copy_state(&sh.g, real + slot, tid);
@@ -683,6 +703,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
         copy_state(real + slot, &sh.g, tid);
     }
     if (tid == 0) { M.ctl[slot] = sh.ctl; if (slot == 0) atomicAdd(&M.counters[6], 1ull); }
+    MPROF_T(me5); MPROF_ADD(12, me4, me5);
 }
 
 // tower-output cache.  z: [2][n][400] as written by the tower for the boards flagged by k_select.  Afterwards
@@ -939,6 +960,14 @@ int trl_mcts_root_children(trl_engine *h, int32_t *counts, uint16_t *moves, int3
 
 // test hook: the stub evaluator on the current leaves (values[n], policy[n][11583], device pointers)
 int trl_debug_stub_eval_salted(trl_engine *h, float *dev_values, float *dev_policy, uint64_t salt);
+#ifdef TRL_PROFILE
+int trl_debug_mcts_prof(unsigned long long *host_out, int reset) {
+    HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mprof), sizeof(unsigned long long) * 16));
+    if (reset) { unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_mprof), z, sizeof z)); }
+    return TRL_OK;
+}
+#endif
+
 int trl_debug_stub_eval(trl_engine *h, float *dev_values, float *dev_policy) {
     return trl_debug_stub_eval_salted(h, dev_values, dev_policy, 0);
 }
