@@ -34,8 +34,10 @@ struct SlotCtl {
     int32_t n_nodes, n_states;
     int32_t leaf, leaf_kind, leaf_nlegal, leaf_state;
     int32_t overflow, leaf_parent_state;      // state index of the leaf's parent (-1 at the root)
+    int32_t depth, pad_;                      // nodes on the selection path root .. leaf (DevMcts::path)
     double  terminal_value;
 };
+constexpr int PATH_CAP = 64;                  // deeper paths are backed up by walking the parent links
 
 struct Tree {               // device pointers, column per node field; slot s owns [s * max_nodes, (s + 1) * max_nodes)
     int32_t  *parent, *first, *visit, *state;
@@ -52,6 +54,7 @@ struct DevMcts {
     SlotCtl *ctl;
     trl_game_state *pool;       // [n_games][cap_states]
     uint16_t *leaf_moves;       // [n_games][TRL_MAX_LEGAL]
+    int32_t *path;              // [n_games][PATH_CAP]: the nodes k_select walked through, for a lane-parallel backup
     trl_record *recs;
     unsigned int *rec_count;
     float *zcache;              // [n_games][cap_states][2 players][400]: tower output per expanded position and board
@@ -176,8 +179,10 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
 
     // SELECT (ai.py:346-393): walk down by arg-max of Q + U, ties to the last child
     MPROF_T(ms1); MPROF_ADD(0, ms0, ms1);
-    int node = 0;
+    int node = 0, depth = 0;
     while (true) {
+        if (tid == 0 && depth < PATH_CAP) M.path[(size_t)slot * PATH_CAP + depth] = node;
+        depth++;
         int n = M.t.nchild[nb + node];
         if (n == 0) break;
         const int first = M.t.first[nb + node];
@@ -297,6 +302,7 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
         SlotCtl &c = sh.ctl;
         c.iter += 1;
         c.leaf = node; c.leaf_kind = kind; c.leaf_nlegal = nlegal; c.leaf_state = sidx; c.leaf_parent_state = pstate;
+        c.depth = depth;
         if (need) {
             // which boards need the tower: a move changes only the mover's board (game.py:66-118), so the side to
             // move at the leaf keeps the tower output its board had in the parent position (trl_mcts_zcache)
@@ -550,42 +556,54 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
 
     // BACKUP (ai.py:504-533) and FPU refresh of the unvisited siblings (ai.py:536-565)
     MPROF_T(me3); MPROF_ADD(10, me2, me3);
-    if (tid == 0) {
-        value = 1.0 - value;
-        const double pos = value, neg = 1.0 - value;
+    {
+        // every node of the path gets the same two numbers, so the walk up the parent links (one dependent global
+        // load per level) is replaced by one lane per level over the path k_select recorded
+        const double bval = 1.0 - value;
+        const double pos = bval, neg = 1.0 - bval;
         const int final_turn = M.t.turn[nb + leaf];
-        for (int n = leaf;; n = M.t.parent[nb + n]) {
-            const size_t i = nb + n;
-            int vc = M.t.visit[i] + 1;
-            double w = M.t.wsum[i] + ((M.t.turn[i] == final_turn) ? pos : neg);
-            M.t.visit[i] = vc; M.t.wsum[i] = w; M.t.q[i] = w / vc;
-            if (n == 0) break;
-        }
-        sh.flag = 0;
-        if (leaf != 0 && cfg.fpu_reduction) {
-            const int par = M.t.parent[nb + leaf];
-            if (par != 0) {
-                const int n = M.t.nchild[nb + par], first = M.t.first[nb + par];
-                float explored = 0.f; bool any = false;
-                for (int k = 0; k < n; k++)
-                    if (M.t.visit[nb + first + k] > 0) {
-                        float p = (float)M.t.prior[nb + first + k];
-                        explored = any ? explored + p : p; any = true;
-                    }
-                double fpu = (1.0 - M.t.q[nb + par]) - cfg.fpu_value * sqrt((double)explored);
-                if (!(fpu > value_min)) fpu = value_min;
-                sh.pd[0] = fpu; sh.flag = 1; sh.chosen = par;
+        const int depth = sh.ctl.depth;
+        if (depth <= PATH_CAP) {
+            if (tid < depth) {
+                const size_t i = nb + M.path[(size_t)slot * PATH_CAP + tid];
+                const int vc = M.t.visit[i] + 1;
+                const double w = M.t.wsum[i] + ((M.t.turn[i] == final_turn) ? pos : neg);
+                M.t.visit[i] = vc; M.t.wsum[i] = w; M.t.q[i] = w / vc;
+            }
+        } else if (tid == 0) {
+            for (int n = leaf;; n = M.t.parent[nb + n]) {
+                const size_t i = nb + n;
+                int vc = M.t.visit[i] + 1;
+                double w = M.t.wsum[i] + ((M.t.turn[i] == final_turn) ? pos : neg);
+                M.t.visit[i] = vc; M.t.wsum[i] = w; M.t.q[i] = w / vc;
+                if (n == 0) break;
             }
         }
+        __threadfence_block();
+        __syncthreads();
+        // FPU refresh: the parent's unvisited children restart from (1 - Q_parent) - reduction * sqrt(sum of the visited
+        // children's priors), the sum taken in float32 and in child order (ai.py:536-565)
+        const int par = (leaf != 0 && cfg.fpu_reduction) ? M.t.parent[nb + leaf] : 0;
+        if (par != 0) {
+            const int n = M.t.nchild[nb + par], first = M.t.first[nb + par];
+            for (int k = tid; k < n; k += BLOCK)
+                sh.pf[k] = (M.t.visit[nb + first + k] > 0) ? (float)M.t.prior[nb + first + k] : -1.f;   // priors are > 0
+            __syncthreads();
+            if (tid == 0) {
+                float explored = 0.f; bool any = false;
+                for (int k = 0; k < n; k++)
+                    if (sh.pf[k] >= 0.f) { explored = any ? explored + sh.pf[k] : sh.pf[k]; any = true; }
+                double fpu = (1.0 - M.t.q[nb + par]) - cfg.fpu_value * sqrt((double)explored);
+                if (!(fpu > value_min)) fpu = value_min;
+                sh.dsum = fpu;
+            }
+            __syncthreads();
+            const double fpu = sh.dsum;
+            for (int k = tid; k < n; k += BLOCK)
+                if (sh.pf[k] < 0.f) M.t.q[nb + first + k] = fpu;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (sh.flag) {
-        const int par = sh.chosen, n = M.t.nchild[nb + par], first = M.t.first[nb + par];
-        const double fpu = sh.pd[0];
-        for (int k = tid; k < n; k += BLOCK)
-            if (M.t.visit[nb + first + k] == 0) M.t.q[nb + first + k] = fpu;
-    }
-    __syncthreads();
 
     // end of the search: choose, record, play (ai.py:568-614, 1610-1695)
     MPROF_T(me4); MPROF_ADD(11, me3, me4);
@@ -784,7 +802,7 @@ struct trl_mcts {
 static void free_dev(DevMcts &d) {
     hipFree(d.t.parent); hipFree(d.t.first); hipFree(d.t.visit); hipFree(d.t.state); hipFree(d.t.nchild); hipFree(d.t.move);
     hipFree(d.t.wsum); hipFree(d.t.q); hipFree(d.t.prior); hipFree(d.t.pf32); hipFree(d.t.turn);
-    hipFree(d.ctl); hipFree(d.pool); hipFree(d.leaf_moves); hipFree(d.recs); hipFree(d.rec_count); hipFree(d.counters);
+    hipFree(d.ctl); hipFree(d.pool); hipFree(d.leaf_moves); hipFree(d.path); hipFree(d.recs); hipFree(d.rec_count); hipFree(d.counters);
     hipFree(d.zcache);
 }
 
@@ -829,6 +847,7 @@ int trl_mcts_create(trl_engine *h, const trl_mcts_config *cfg) {
     HIPCHK(hipMalloc(&d.ctl, n * sizeof(SlotCtl)));
     HIPCHK(hipMalloc(&d.pool, n * d.cap_states * sizeof(trl_game_state)));
     HIPCHK(hipMalloc(&d.leaf_moves, n * TRL_MAX_LEGAL * 2));
+    HIPCHK(hipMalloc(&d.path, n * PATH_CAP * sizeof(int32_t)));
     HIPCHK(hipMalloc(&d.zcache, n * d.cap_states * 800 * sizeof(float)));
     HIPCHK(hipMalloc(&d.recs, (size_t)d.rec_cap * sizeof(trl_record)));
     HIPCHK(hipMalloc(&d.rec_count, 4));
