@@ -269,6 +269,9 @@ int  trl_mcts_select(trl_engine *h, float *dev_grids, float *dev_vec);
  *                         fills in the reused ones from the parent's cache entry and stores both outputs in the
  *                         leaf's entry, so that afterwards dev_z is complete for the heads. */
 int  trl_mcts_select_need(trl_engine *h, float *dev_grids, float *dev_vec, uint8_t *dev_need);
+/* floats of tower output per board the cache holds (default 400 = AlphaSame's process_grid output; the BaseResNet
+ * family caches its (own_kernels + 1) x 400 raw projections).  Call before the first tick: the cache is reallocated. */
+int  trl_mcts_zcache_dim(trl_engine *h, int floats_per_board);
 int  trl_mcts_zcache(trl_engine *h, float *dev_z);
 /* tick part B.  dev_values: float[n_games] (sigmoid value head), dev_policy: float[n_games][11583]
  * softmaxed policy, both as evaluate() returns them (ai.py:1222-1319). */

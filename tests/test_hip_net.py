@@ -281,6 +281,26 @@ def test_tower_cache_is_bit_identical():
     assert np.array_equal(a["state"], b["state"])
 
 
+def test_tower_cache_with_the_default_net_family():
+    """BaseResNet on the fused tower: caching the five raw projections per board (trl_mcts_zcache_dim = 2000 floats)
+    gives the same games as evaluating both boards at every leaf"""
+    torch.manual_seed(0)
+    mc = trl.BaseResNetConfig(blocks=2, filters=32, opp_hidden=16, own_kernels=4, value_hidden=8)
+    net = trl.BaseResNet(mc)
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=24, training=True)
+    out = []
+    for cache in (True, False):
+        sp = trl.SelfPlay(cfg, net, 64, seed=21, tower_cache=cache)
+        assert sp.tower_cache == cache and sp.heads is None
+        sp.tick(260)
+        r = sp.drain()
+        out.append(r[np.lexsort((r["kind"], r["ply"], r["slot"], r["episode"]))])
+    a, b = out
+    assert len(a) == len(b) > 64
+    assert np.array_equal(a["chosen"], b["chosen"]) and np.array_equal(a["visits"], b["visits"])
+    assert np.array_equal(a["state"], b["state"])
+
+
 def test_device_heads_match_torch_heads():
     """trl_mcts_expand_alphasame (dense heads + cache assembly inside the expand kernel) against the PyTorch
     heads: same root children, priors and Q to float32 rounding, nearly all first moves equal"""

@@ -57,7 +57,8 @@ struct DevMcts {
     int32_t *path;              // [n_games][PATH_CAP]: the nodes k_select walked through, for a lane-parallel backup
     trl_record *recs;
     unsigned int *rec_count;
-    float *zcache;              // [n_games][cap_states][2 players][400]: tower output per expanded position and board
+    float *zcache;              // [n_games][cap_states][2 players][zdim]: tower output per expanded position and board
+    int zdim;                   // floats per board: 400 for AlphaSame; (own_kernels + 1) * 400 for the BaseResNet family
     unsigned long long *counters;   // 0 simulations, 1 moves, 2 games, 3 dropped, 4 max nodes, 5 overflow, 6 ticks
 };
 
@@ -733,15 +734,16 @@ __global__ __launch_bounds__(128) void k_zcache(DevMcts M, float *z) {
     if (c.phase != 1 || c.leaf_kind == 2) return;
     const trl_game_state *pool = M.pool + (size_t)slot * M.cap_states;
     const int q = pool[c.leaf_state].turn;                       // side to move at the leaf
-    float *zc = M.zcache + ((size_t)slot * M.cap_states) * 800;
-    float *mine = zc + (size_t)c.leaf_state * 800;
-    float *za = z + (size_t)slot * 400, *zo = z + ((size_t)M.n_games + slot) * 400;
-    for (int i = tid; i < 400; i += 128) {
-        float a = (c.leaf_parent_state < 0) ? za[i] : zc[(size_t)c.leaf_parent_state * 800 + q * 400 + i];
+    const int zd = M.zdim;
+    float *zc = M.zcache + ((size_t)slot * M.cap_states) * 2 * zd;
+    float *mine = zc + (size_t)c.leaf_state * 2 * zd;
+    float *za = z + (size_t)slot * zd, *zo = z + ((size_t)M.n_games + slot) * zd;
+    for (int i = tid; i < zd; i += 128) {
+        float a = (c.leaf_parent_state < 0) ? za[i] : zc[(size_t)c.leaf_parent_state * 2 * zd + q * zd + i];
         float o = zo[i];
         za[i] = a;
-        mine[q * 400 + i] = a;
-        mine[(1 - q) * 400 + i] = o;
+        mine[q * zd + i] = a;
+        mine[(1 - q) * zd + i] = o;
     }
 }
 
@@ -848,7 +850,8 @@ int trl_mcts_create(trl_engine *h, const trl_mcts_config *cfg) {
     HIPCHK(hipMalloc(&d.pool, n * d.cap_states * sizeof(trl_game_state)));
     HIPCHK(hipMalloc(&d.leaf_moves, n * TRL_MAX_LEGAL * 2));
     HIPCHK(hipMalloc(&d.path, n * PATH_CAP * sizeof(int32_t)));
-    HIPCHK(hipMalloc(&d.zcache, n * d.cap_states * 800 * sizeof(float)));
+    d.zdim = 400;
+    HIPCHK(hipMalloc(&d.zcache, n * d.cap_states * 2 * d.zdim * sizeof(float)));
     HIPCHK(hipMalloc(&d.recs, (size_t)d.rec_cap * sizeof(trl_record)));
     HIPCHK(hipMalloc(&d.rec_count, 4));
     HIPCHK(hipMalloc(&d.counters, 8 * 8));
@@ -873,6 +876,20 @@ int trl_mcts_select_need(trl_engine *h, float *dev_grids, float *dev_vec, uint8_
     HIPCHK(hipSetDevice(h->cfg.device));
     hipLaunchKernelGGL(k_select, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_grids, dev_vec, dev_need);
     HIPCHK(hipGetLastError());
+    return TRL_OK;
+}
+
+int trl_mcts_zcache_dim(trl_engine *h, int floats_per_board) {
+    if (!h || !h->mcts || floats_per_board < 1 || floats_per_board > 8 * 400)
+        return fail(TRL_E_INVALID, "trl_mcts_zcache_dim: %s", "bad argument / no search attached");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    DevMcts &d = h->mcts->d;
+    if (floats_per_board == d.zdim) return TRL_OK;
+    HIPCHK(hipFree(d.zcache));
+    d.zcache = nullptr;
+    d.zdim = floats_per_board;
+    HIPCHK(hipMalloc(&d.zcache, (size_t)d.n_games * d.cap_states * 2 * d.zdim * sizeof(float)));
     return TRL_OK;
 }
 
@@ -911,6 +928,7 @@ int trl_mcts_expand_alphasame(trl_engine *h, const float *dev_z, const float *de
         !w->value3_w || !w->policy_w || !w->policy_b)
         return fail(TRL_E_INVALID, "trl_mcts_expand_alphasame: %s", "null argument / no search attached");
     HIPCHK(hipSetDevice(h->cfg.device));
+    if (h->mcts->d.zdim != 400) return fail(TRL_E_STATE, "%s", "trl_mcts_expand_alphasame needs the 400-float tower cache (trl_mcts_zcache_dim)");
     HeadsDev H{w->oside_w, w->oside_b, w->value0_w, w->value0_b, w->value3_w, w->value3_b, w->use_tanh};
     hipLaunchKernelGGL(k_expand<2>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_vec,
                        dev_z, w->policy_w, w->policy_b, 521, H);

@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "trl_env_rollout_random", "trl_last_kernel_ms",
     "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_expand_head", "trl_mcts_drain_records", "trl_mcts_get_stats",
     "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16", "trl_alphasame_trunk16_need", "trl_alphasame_trunk", "trl_resnet_trunk", "trl_graph_begin", "trl_graph_end", "trl_graph_launch",
-    "trl_mcts_select_need", "trl_mcts_zcache", "trl_mcts_expand_alphasame",
+    "trl_mcts_select_need", "trl_mcts_zcache", "trl_mcts_zcache_dim", "trl_mcts_expand_alphasame",
 ]
 
 GRID_FLOATS = 400
@@ -127,6 +127,7 @@ def load_library(path=None):
     L.trl_mcts_root_children.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     L.trl_mcts_select_need.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.trl_mcts_zcache.argtypes = [C.c_void_p, C.c_void_p]
+    L.trl_mcts_zcache_dim.argtypes = [C.c_void_p, C.c_int]
     L.trl_graph_begin.argtypes = [C.c_void_p]
     L.trl_graph_end.argtypes = [C.c_void_p]
     L.trl_graph_launch.argtypes = [C.c_void_p, C.c_int]
@@ -257,6 +258,9 @@ class Engine:
 
     def graph_launch(self, n=1):
         _check(self._L, self._L.trl_graph_launch(self._h, int(n)), "trl_graph_launch")
+
+    def mcts_zcache_dim(self, floats_per_board):
+        _check(self._L, self._L.trl_mcts_zcache_dim(self._h, int(floats_per_board)), "trl_mcts_zcache_dim")
 
     def mcts_zcache(self, z_ptr):
         _check(self._L, self._L.trl_mcts_zcache(self._h, z_ptr), "trl_mcts_zcache")

@@ -187,6 +187,8 @@ class AlphaSame(nn.Module):
         fd = self._folded or self.prepare()._folded
         return fd["packed_tower"] is not None and self.use_hip_trunk
 
+    tower_floats_per_board = ROWS * COLS
+
     def device_heads(self):
         """trl_alphasame_heads for trl_mcts_expand_alphasame (pointers into the folded tensors of prepare())"""
         from . import engine as _eng
@@ -351,16 +353,19 @@ class BaseResNet(nn.Module):
         self._folded = fd
         return self
 
-    def _tower_hip(self, boards, packed):
-        """-> float[m, own_kernels + 1, 400]: raw 1x1 projections of the final feature map (trl_resnet_trunk)"""
+    def _tower_hip(self, boards, packed, need=None):
+        """-> float[m, own_kernels + 1, 400]: raw 1x1 projections of the final feature map (trl_resnet_trunk);
+        need: optional uint8 [m] -- boards with 0 are skipped (their rows are zero)"""
         from . import engine as _eng
         L = _eng.load_library()
         m = boards.shape[0]
         kout = self.model_config.own_kernels + 1
         x = boards.reshape(m, ROWS * COLS).contiguous()
-        out = torch.empty((m, kout, ROWS * COLS), dtype=torch.float32, device=boards.device)
+        alloc = torch.empty if need is None else torch.zeros
+        out = alloc((m, kout, ROWS * COLS), dtype=torch.float32, device=boards.device)
         rc = L.trl_resnet_trunk(x.data_ptr(), m, packed.data_ptr(), self.model_config.filters, len(self.trunk), kout,
-                                out.data_ptr(), None, torch.cuda.current_stream(boards.device).cuda_stream)
+                                out.data_ptr(), None if need is None else need.data_ptr(),
+                                torch.cuda.current_stream(boards.device).cuda_stream)
         if rc != 0:
             raise _eng.EngineError("trl_resnet_trunk failed: %s" % L.trl_last_error().decode())
         return out
@@ -375,14 +380,34 @@ class BaseResNet(nn.Module):
         self._folded = None
         return r
 
+    @property
+    def supports_tower_cache(self):
+        """True when the tower runs as the fused HIP kernel (it can skip boards; trl_mcts_zcache flow)"""
+        fd = self._folded or self.prepare()._folded
+        return fd["packed_tower"] is not None and self.use_hip_trunk
+
+    @property
+    def tower_floats_per_board(self):
+        return (self.model_config.own_kernels + 1) * ROWS * COLS
+
     @torch.no_grad()
-    def head_inputs(self, grids, vec):
+    def tower_need(self, grids, need):
+        """raw tower projections [2n, (own_kernels + 1) * 400] of the boards flagged in need (uint8 [2n])"""
+        fd = self._folded or self.prepare()._folded
+        n2 = grids.shape[0] * grids.shape[1]
+        return self._tower_hip(grids.reshape(n2, ROWS * COLS), fd["packed_tower"], need).reshape(n2, -1)
+
+    @torch.no_grad()
+    def head_inputs(self, grids, vec, z=None):
+        """z: precomputed tower projections [2n, (own_kernels + 1) * 400] (side to move first), else the tower runs"""
         fd = self._folded or self.prepare()._folded
         n = vec.shape[0]
         a_extra, o_extra, color = vec[:, :52], vec[:, 52:104], vec[:, 104:105]
-        hip = fd["packed_tower"] is not None and self.use_hip_trunk
+        hip = z is not None or (fd["packed_tower"] is not None and self.use_hip_trunk)
         if hip:
-            z = self._tower_hip(grids.reshape(2 * n, ROWS * COLS), fd["packed_tower"])
+            if z is None:
+                z = self._tower_hip(grids.reshape(2 * n, ROWS * COLS), fd["packed_tower"])
+            z = z.reshape(2 * n, self.model_config.own_kernels + 1, ROWS * COLS)
             k = self.model_config.own_kernels
             o_col = torch.relu(z[n:, k] + fd["opp"][1])
         else:
@@ -415,8 +440,8 @@ class BaseResNet(nn.Module):
         return (torch.tanh(v) if self.use_tanh else torch.sigmoid(v)), torch.softmax(logits, dim=1)
 
     @torch.no_grad()
-    def evaluate_head_inputs(self, grids, vec):
-        v, hx = self.head_inputs(grids, vec)
+    def evaluate_head_inputs(self, grids, vec, z=None):
+        v, hx = self.head_inputs(grids, vec, z)
         return (torch.tanh(v) if self.use_tanh else torch.sigmoid(v)), hx
 
     def _pack(self, a_grid, a_pieces, a_b2b, a_combo, a_garbage, o_grid, o_pieces, o_b2b, o_combo, o_garbage, color):

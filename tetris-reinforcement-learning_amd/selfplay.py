@@ -136,6 +136,8 @@ class SelfPlay:
             self.vec = torch.zeros((self.n, _eng.VEC_FLOATS), dtype=torch.float32, device=self.device)
             self.need = torch.ones(2 * self.n, dtype=torch.uint8, device=self.device)
         self.tower_cache = self.tower_cache and policy_head == "legal" and getattr(self.net, "supports_tower_cache", False)
+        if self.tower_cache:
+            self.engine.mcts_zcache_dim(self.net.tower_floats_per_board)
         # every head of AlphaSame inside the expand kernel (trl_mcts_expand_alphasame): the tick is three HIP kernels
         self.heads = self.net.device_heads() if (self.tower_cache and device_heads and hasattr(self.net, "device_heads")) else None
         if self.heads is not None:
