@@ -26,9 +26,13 @@ constexpr int QCAP  = 1024;        // FIFO capacity per search (observed max 511
 constexpr int SPAWN_Y = TRL_ROWS - TRL_SPAWN_ROW;   // 17
 
 // LDS scratch of one wavefront's search
+// Member order matters: rows 0, 1, 42 and 43 of every validity map are all-zero (a piece origin that high or low
+// puts a cell outside the 40 rows) and visited / present bits are subsets of valid ones, so the two rows before and
+// after valid[r] -- the end of visited[3] or valid[r-1], the start of valid[r+1] or present[0] -- are zero guard rows:
+// the kick probes read valid[r][y] for y in [-2, 45] without clamping or bounds tests.
 struct alignas(4) MgScratch {
-    uint16_t valid[4][MAP_H];      // valid[r][ym] bit xm: piece (rotation r) at origin (xm-2, ym-2) fits
     uint16_t visited[4][MAP_H];
+    uint16_t valid[4][MAP_H];      // valid[r][ym] bit xm: piece (rotation r) at origin (xm-2, ym-2) fits; bits 14, 15 zero
     uint16_t present[4][MAP_H];    // unflagged placements
     uint16_t flagp[4][MAP_H];      // placements reached by a rotation (rotation_just_occurred)
     uint16_t ulp[4][MAP_H];        // ... whose last writer used the last kick of its list
@@ -267,23 +271,23 @@ static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int typ
                 const uint64_t kt = dir == 1 ? kt1 : (dir == 2 ? kt2 : kt3);
                 const int nk = (int)(kt >> 60);
                 const uint16_t *vrow = S.valid[nrot];
-                int txs[6], tys[6]; uint32_t vv[6];
+                // fit mask of the (up to six) kicks of this probe, bit ki = kick ki lands on a valid cell.  No bounds
+                // tests: x in [-2, 15] selects a bit of the 16-bit row whose bits 14, 15 are zero, y in [-2, 45] reads
+                // zero guard rows (MgScratch).  The first fitting kick is the reference's (:452-470).
+                const int colm2 = col - 2, fyp2 = fy + 2;
+                uint32_t fitm = 0;
 #pragma unroll
                 for (int ki = 0; ki < 6; ki++) {
-                    txs[ki] = col + (int)((kt >> (6 * ki)) & 7) - 2;
-                    tys[ki] = fy - ((int)((kt >> (6 * ki + 3)) & 7) - 2);
-                    int tyc = tys[ki] < 0 ? 0 : (tys[ki] > MAP_H - 1 ? MAP_H - 1 : tys[ki]);
-                    vv[ki] = vrow[tyc];
+                    const int tx = colm2 + (int)((kt >> (6 * ki)) & 7);
+                    const int ty = fyp2 - (int)((kt >> (6 * ki + 3)) & 7);
+                    fitm |= (((uint32_t)vrow[ty] >> (tx & 15)) & 1u) << ki;
                 }
-                int found_i = 0, nmx = 0, nmy = 0, kidx = 0, done = 0;
-#pragma unroll
-                for (int ki = 0; ki < 6; ki++) {
-                    int in = (int)((unsigned)txs[ki] < (unsigned)MAP_W) & (int)((unsigned)tys[ki] < (unsigned)MAP_H);
-                    int fit = in & (int)((vv[ki] >> (txs[ki] & 15)) & 1) & (int)(ki < nk) & (int)probe & (done ^ 1);
-                    found_i = fit ? (int)(tys[ki] >= 2) : found_i;                      // new_y < 0: discard (:462-463)
-                    nmx = fit ? txs[ki] : nmx; nmy = fit ? tys[ki] : nmy; kidx = fit ? ki : kidx;
-                    done |= fit;
-                }
+                fitm &= (1u << nk) - 1u;
+                fitm = probe ? fitm : 0u;
+                const int kidx = fitm ? (__ffs((int)fitm) - 1) : 0;
+                const uint32_t kk2 = (uint32_t)(kt >> (6 * kidx));
+                const int nmx = colm2 + (int)(kk2 & 7), nmy = fyp2 - (int)((kk2 >> 3) & 7);
+                const int found_i = (fitm != 0) & (nmy >= 2);                          // new_y < 0: discard (:462-463)
                 const bool found = found_i != 0;
                 int nul = (isT && dir != 2 && kidx == nk - 1) ? 1 : 0;
                 uint32_t nbit = 1u << nmx;
