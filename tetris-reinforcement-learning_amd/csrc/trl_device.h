@@ -51,12 +51,17 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ int lane_rank(uint64_t mask, int lane) {
     return __popcll(mask & ((1ull << lane) - 1ull));
 }
+// inclusive prefix sum over the 64 lanes (all active) with DPP moves in the vector ALU: four row_shr steps scan each
+// row of 16 lanes, row_bcast:15 / row_bcast:31 carry the row totals across (rows 1, 3 and rows 2, 3).  A scan
+// through __shfl_up is six dependent ds_bpermute round trips instead.
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+    (void)lane;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
     return v;
 }
 
@@ -214,7 +219,8 @@ static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int typ
             if (first == 64) { int n = tail - head; head += (n < 64 ? n : 64); continue; }
             head += first + 1;
 
-            int fmx = uni(__shfl(mx, first, 64)), fmy = uni(__shfl(my, first, 64)), frot = uni(__shfl(rot, first, 64));
+            const uint32_t fit = (uint32_t)__builtin_amdgcn_readlane((int)it, first);      // `first` is wave-uniform
+            const int fmx = fit & 15, fmy = (fit >> 4) & 63, frot = (fit >> 10) & 3;
             if (!((S.valid[frot][fmy] >> fmx) & 1)) continue;                          // :406-407
 
             // (1) scanline flood fill of this rotation state, one row per iteration (:409-425, :485-488); wave-uniform.
@@ -247,7 +253,7 @@ static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int typ
                 int cnt = __popc(e);
                 int incl = wave_incl_scan(cnt, lane);
                 int off = incl - cnt;
-                n_edges = uni(__shfl(incl, 63, 64));
+                n_edges = __builtin_amdgcn_readlane(incl, 63);
                 if (n_edges > out_cap) { *overflow = 1; n_edges = out_cap; }
                 while (e) {
                     int c = __ffs((int)e) - 1; e &= e - 1;
@@ -340,7 +346,7 @@ static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int typ
                     if (off < out_cap) out[off] = (uint16_t)TRL_MOVE(plane, row, c);
                     off++;
                 }
-                total += uni(__shfl(incl, 63, 64));
+                total += __builtin_amdgcn_readlane(incl, 63);
             }
         }
         if (total > out_cap) { *overflow = 1; total = out_cap; }
