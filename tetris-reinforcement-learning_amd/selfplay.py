@@ -313,6 +313,32 @@ def _play_raw(config, network, num_games, seed, device=0, max_slots=1024, stream
     return recs[np.lexsort((recs["kind"], recs["ply"], recs["slot"], recs["episode"]))]
 
 
+def _play_collect(config, network, num_games, seed, device=0, max_slots=1024, streams=None, as_text=False):
+    """_play_raw + games_from_records in one pass, with the host's record conversion overlapped with the device: the
+    next 64 ticks are enqueued before the records of the previous 64 are turned into training records."""
+    slots = min(int(num_games), int(max_slots))
+    sp = SelfPlay(config, network, slots, seed=seed, device=device, streams=streams, auto_reset=num_games > slots)
+    col = GameCollector(config, as_text=as_text)
+    ended = []
+    sp.tick(64)
+    while True:
+        r = sp.drain()
+        ended += [(int(e), int(sl)) for e, sl in zip(r["episode"][r["kind"] == _eng.REC_GAME_END], r["slot"][r["kind"] == _eng.REC_GAME_END])]
+        st = sp.stats()
+        if st["records_dropped"] or st["overflow"]:
+            raise _eng.EngineError("device record buffer or tree capacity overflowed: %r" % (st,))
+        done = len(ended) >= num_games
+        if not done:
+            sp.tick(64)                                   # the device goes on while the host converts
+        col.add(r[np.lexsort((r["kind"], r["ply"], r["slot"], r["episode"]))])
+        if done:
+            break
+    keep = set(sorted(ended)[:num_games])                 # (episode, slot)
+    games = [g for g in col.finished if (g["key"][1], g["key"][0]) in keep]
+    games.sort(key=lambda g: (g["key"][1], g["key"][0]))
+    return games
+
+
 def games_from_records(config, recs, as_text=False):
     """raw records (possibly gathered from several ranks) -> finished games in (episode, slot) order;
     as_text: g["data"] holds each record as JSON text (bytes) instead of the 13-field list"""
@@ -345,8 +371,8 @@ def _run_games(config, network, num_games, seed, device=0, max_slots=1024, strea
             return [], None
         allrecs = np.concatenate([np.frombuffer(p.tobytes(), dtype=_eng.RECORD_DTYPE) for p in parts])
         return games_from_records(config, allrecs, as_text)[:num_games], None
-    recs = _play_raw(config, network, num_games, seed, device=device, max_slots=max_slots, streams=streams)
-    return games_from_records(config, recs, as_text)[:num_games], None
+    return _play_collect(config, network, num_games, seed, device=device, max_slots=max_slots, streams=streams,
+                         as_text=as_text)[:num_games], None
 
 
 def play_game(config, interference_network, game_number=None, screen=None, seed=0):
