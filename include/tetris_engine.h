@@ -298,6 +298,11 @@ typedef struct trl_alphasame_heads {
     int32_t use_tanh;                     /* output activation of the value head: 0 sigmoid, 1 tanh     */
 } trl_alphasame_heads;
 int  trl_mcts_expand_alphasame(trl_engine *h, const float *dev_z, const float *dev_vec, const trl_alphasame_heads *w);
+/* the same for the slots with dev_slot_mask[slot] == want only (uint8 per slot): matches between two networks run one
+ * launch per network (battle_networks, ai.py:1975-2052: a player's searches use that player's network); `last` = 1
+ * on the launch that completes the tick. */
+int  trl_mcts_expand_alphasame_masked(trl_engine *h, const float *dev_z, const float *dev_vec, const trl_alphasame_heads *w,
+                                      const uint8_t *dev_slot_mask, int want, int last);
 /* copy out and clear the pending records (host buffer of `cap` records); returns the count in *n_out */
 int  trl_mcts_drain_records(trl_engine *h, trl_record *host_out, int cap, int *n_out);
 int  trl_mcts_get_stats(trl_engine *h, trl_mcts_stats *host_out);

@@ -63,3 +63,24 @@ def test_battle_networks_signature_and_threshold():
     assert gating._check_threshold(np.array([6.0, 4.0]), 10, 0.55, "more") is True
     assert gating._check_threshold(np.array([4.0, 6.0]), 10, 0.55, "moreorequal") is False
     assert gating._check_threshold(np.array([5.0, 4.0]), 10, 0.55, "more") is None
+
+
+def test_native_two_network_tick():
+    """battle_networks with two AlphaSame nets on the fused tower: one tower per leaf and one expand launch per
+    network (trl_mcts_expand_alphasame_masked) -- deterministic, every game decided, and the same first moves as
+    the generic path that runs both nets' full forward pass over every slot (float32 rounding of the heads aside)"""
+    mc = trl.AlphaSameConfig(blocks=2, filters=16)
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=16, training=False)
+    torch.manual_seed(3); a = trl.AlphaSame(mc).cuda().prepare()
+    torch.manual_seed(4); b = trl.AlphaSame(mc).cuda().prepare()
+    games = 32
+    runs = []
+    for native in (True, True, False):
+        bt = gating.Battle(cfg, a.evaluate_packed, b.evaluate_packed, games, seed=9, nets=(a, b) if native else None)
+        assert (bt.nets is not None) == native
+        wins = bt.run()
+        assert wins.sum() == games
+        runs.append((wins, {g: [m for _, m in sorted(v)] for g, v in bt.moves.items()}))
+    assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+    same_first = sum(runs[0][1][g][0] == runs[2][1][g][0] for g in range(games))
+    assert same_first >= games - 2

@@ -37,6 +37,7 @@ struct alignas(4) MgScratch {
     uint16_t flagp[4][MAP_H];      // placements reached by a rotation (rotation_just_occurred)
     uint16_t ulp[4][MAP_H];        // ... whose last writer used the last kick of its list
     uint16_t queue[QCAP];          // mx:4 | my:6 | rot:2 | flag:1 | last_kick:1
+    uint16_t edge[MAP_H];          // edge-cell mask of each row of the flood in progress
 };
 
 // ---- wave helpers -------------------------------------------------------------------------
@@ -50,14 +51,6 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ int lane_rank(uint64_t mask, int lane) {
     return __popcll(mask & ((1ull << lane) - 1ull));
 }
-// v_writelane_b32: put a wave-uniform value into one lane of a vector register (the clang in this ROCm has no builtin
-// for it).  Value and lane select are scalar registers; the lane select must not come straight from a vector-ALU
-// instruction (4 wait states on gfx9) -- the callers pass loop counters.
-__device__ __forceinline__ int writelane(int value, int lane_select, int old) {
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(value), "s"(lane_select));
-    return old;
-}
-
 // inclusive prefix sum over the 64 lanes (all active) with DPP moves in the vector ALU: four row_shr steps scan each
 // row of 16 lanes, row_bcast:15 / row_bcast:31 carry the row totals across (rows 1, 3 and rows 2, 3).  A scan
 // through __shfl_up is six dependent ds_bpermute round trips instead.
@@ -233,35 +226,22 @@ static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int typ
             // (1) scanline flood fill of this rotation state, one row per iteration (:409-425, :485-488); wave-uniform.
             //     The kick probes of the reference's inner loop only read the OTHER rotations' visited maps, which
             //     this item does not change, so they are deferred until the whole flood is known.
-            //     The rotation's rows live in registers for the duration of the flood, row y in lane y: a row is
-            //     fetched with v_readlane into scalar registers, the fill and the edge tests run on the scalar ALU
-            //     (the kernel is vector-ALU bound), results go back with v_writelane; LDS sees one read and one
-            //     write of the rotation's maps per flood instead of several per row.
-            const int lrow = lane < MAP_H ? lane : MAP_H - 1;
-            int vreg = S.valid[frot][lrow], visreg = S.visited[frot][lrow];
-            int blkreg = 0, edgereg = 0;
             uint32_t r = 1u << fmx;
             int nrows = 0;
-            uint32_t vr = (uint32_t)__builtin_amdgcn_readlane(vreg, fmy), fvis = (uint32_t)__builtin_amdgcn_readlane(visreg, fmy);
             for (int fy = fmy; fy < MAP_H && r; ++fy, ++nrows) {
-                r = row_fill(vr & ~fvis, r);
-                uint32_t next_vr = 0u, next_vis = 0u;
-                if (fy + 1 < MAP_H) {
-                    next_vr = (uint32_t)__builtin_amdgcn_readlane(vreg, fy + 1);
-                    next_vis = (uint32_t)__builtin_amdgcn_readlane(visreg, fy + 1);
+                uint32_t vr = S.valid[frot][fy];
+                uint32_t unvis = vr & ~(uint32_t)S.visited[frot][fy];
+                r = row_fill(unvis, r);
+                uint32_t next_vr = (fy + 1 < MAP_H) ? (uint32_t)S.valid[frot][fy + 1] : 0u;
+                uint32_t next_vis = (fy + 1 < MAP_H) ? (uint32_t)S.visited[frot][fy + 1] : 0u;
+                uint32_t blocked_down = r & ~next_vr;
+                uint32_t edges = blocked_down | (r & ~(vr << 1)) | (r & ~(vr >> 1));
+                if (lane == 0) {
+                    S.visited[frot][fy] |= (uint16_t)r;
+                    S.present[frot][fy] |= (uint16_t)blocked_down;                     // :439-440
+                    S.edge[nrows] = (uint16_t)edges;
                 }
-                const uint32_t blocked_down = r & ~next_vr;
-                const uint32_t edges = blocked_down | (r & ~(vr << 1)) | (r & ~(vr >> 1));
-                visreg = writelane((int)(fvis | r), fy, visreg);
-                blkreg = writelane((int)blocked_down, fy, blkreg);    // :439-440
-                edgereg = writelane((int)edges, fy, edgereg);
                 r = r & next_vr & ~next_vis;
-                vr = next_vr; fvis = next_vis;
-            }
-            const bool mine = lane >= fmy && lane < fmy + nrows;
-            if (mine) {
-                S.visited[frot][lane] = (uint16_t)visreg;
-                S.present[frot][lane] |= (uint16_t)blkreg;
             }
             wave_sync();
             PROF_T(q2); PROF_ADD(2, q1, q2); PROF_ADD(9, 0ull, (unsigned long long)nrows);
@@ -269,7 +249,7 @@ static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int typ
             // (2) edge cells of all rows, compacted in (row, column) order: lane = row
             int n_edges;
             {
-                uint32_t e = mine ? (uint32_t)edgereg : 0u;
+                uint32_t e = (lane < nrows) ? (uint32_t)S.edge[lane] : 0u;
                 int cnt = __popc(e);
                 int incl = wave_incl_scan(cnt, lane);
                 int off = incl - cnt;
@@ -277,7 +257,7 @@ static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int typ
                 if (n_edges > out_cap) { *overflow = 1; n_edges = out_cap; }
                 while (e) {
                     int c = __ffs((int)e) - 1; e &= e - 1;
-                    if (off < out_cap) task[off] = (uint16_t)((lane << 4) | c);
+                    if (off < out_cap) task[off] = (uint16_t)(((fmy + lane) << 4) | c);
                     off++;
                 }
             }

@@ -338,6 +338,8 @@ struct HeadsDev {
     const float *v3_w;                   // [16]
     float v3_b;
     int use_tanh;
+    const uint8_t *slot_mask;            // optional: only slots with slot_mask[slot] == mask_want are processed
+    int mask_want;                       // (two-network matches: one launch per network, gating.Battle)
 };
 
 template <int MODE>
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
     trl_game_state *pool = M.pool + (size_t)slot * M.cap_states;
     const trl_mcts_config &cfg = M.cfg;
     MPROF_T(me0);
+    if (H.slot_mask && H.slot_mask[slot] != (uint8_t)H.mask_want) return;
     if (tid == 0) sh.ctl = M.ctl[slot];
     __syncthreads();
     if (sh.ctl.phase != 1) return;
@@ -905,7 +908,7 @@ int trl_mcts_expand(trl_engine *h, const float *dev_values, const float *dev_pol
     if (!h || !h->mcts || !dev_values || !dev_policy) return fail(TRL_E_INVALID, "trl_mcts_expand: %s", "null argument / no search attached");
     HIPCHK(hipSetDevice(h->cfg.device));
     hipLaunchKernelGGL(k_expand<0>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_values,
-                       dev_policy, (const float *)nullptr, (const float *)nullptr, 0, HeadsDev{});
+                       dev_policy, (const float *)nullptr, (const float *)nullptr, 0, HeadsDev{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0});
     HIPCHK(hipGetLastError());
     h->mcts->ticks++;
     return TRL_OK;
@@ -917,24 +920,29 @@ int trl_mcts_expand_head(trl_engine *h, const float *dev_values, const float *de
         return fail(TRL_E_INVALID, "trl_mcts_expand_head: %s", "bad argument / no search attached");
     HIPCHK(hipSetDevice(h->cfg.device));
     hipLaunchKernelGGL(k_expand<1>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_values,
-                       dev_feats, dev_head_weight, dev_head_bias, feat_dim, HeadsDev{});
+                       dev_feats, dev_head_weight, dev_head_bias, feat_dim, HeadsDev{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0});
     HIPCHK(hipGetLastError());
     h->mcts->ticks++;
     return TRL_OK;
 }
 
-int trl_mcts_expand_alphasame(trl_engine *h, const float *dev_z, const float *dev_vec, const trl_alphasame_heads *w) {
+int trl_mcts_expand_alphasame_masked(trl_engine *h, const float *dev_z, const float *dev_vec, const trl_alphasame_heads *w,
+                                     const uint8_t *dev_slot_mask, int want, int last) {
     if (!h || !h->mcts || !dev_z || !dev_vec || !w || !w->oside_w || !w->oside_b || !w->value0_w || !w->value0_b ||
         !w->value3_w || !w->policy_w || !w->policy_b)
         return fail(TRL_E_INVALID, "trl_mcts_expand_alphasame: %s", "null argument / no search attached");
     HIPCHK(hipSetDevice(h->cfg.device));
     if (h->mcts->d.zdim != 400) return fail(TRL_E_STATE, "%s", "trl_mcts_expand_alphasame needs the 400-float tower cache (trl_mcts_zcache_dim)");
-    HeadsDev H{w->oside_w, w->oside_b, w->value0_w, w->value0_b, w->value3_w, w->value3_b, w->use_tanh};
+    HeadsDev H{w->oside_w, w->oside_b, w->value0_w, w->value0_b, w->value3_w, w->value3_b, w->use_tanh, dev_slot_mask, want};
     hipLaunchKernelGGL(k_expand<2>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_vec,
                        dev_z, w->policy_w, w->policy_b, 521, H);
     HIPCHK(hipGetLastError());
-    h->mcts->ticks++;
+    if (last) h->mcts->ticks++;
     return TRL_OK;
+}
+
+int trl_mcts_expand_alphasame(trl_engine *h, const float *dev_z, const float *dev_vec, const trl_alphasame_heads *w) {
+    return trl_mcts_expand_alphasame_masked(h, dev_z, dev_vec, w, nullptr, 0, 1);
 }
 
 int trl_mcts_drain_records(trl_engine *h, trl_record *host_out, int cap, int *n_out) {

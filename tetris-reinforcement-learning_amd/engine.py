@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "trl_env_rollout_random", "trl_last_kernel_ms",
     "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_expand_head", "trl_mcts_drain_records", "trl_mcts_get_stats",
     "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16", "trl_alphasame_trunk16_need", "trl_alphasame_trunk", "trl_resnet_trunk", "trl_graph_begin", "trl_graph_end", "trl_graph_launch",
-    "trl_mcts_select_need", "trl_mcts_zcache", "trl_mcts_zcache_dim", "trl_mcts_expand_alphasame",
+    "trl_mcts_select_need", "trl_mcts_expand_alphasame_masked", "trl_mcts_zcache", "trl_mcts_zcache_dim", "trl_mcts_expand_alphasame",
 ]
 
 GRID_FLOATS = 400
@@ -132,6 +132,8 @@ def load_library(path=None):
     L.trl_graph_end.argtypes = [C.c_void_p]
     L.trl_graph_launch.argtypes = [C.c_void_p, C.c_int]
     L.trl_mcts_expand_alphasame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(TrlAlphaSameHeads)]
+    L.trl_mcts_expand_alphasame_masked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(TrlAlphaSameHeads),
+                                                   C.c_void_p, C.c_int, C.c_int]
     L.trl_alphasame_trunk16_need.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.trl_alphasame_trunk16.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.trl_alphasame_trunk.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -267,6 +269,10 @@ class Engine:
 
     def mcts_expand_alphasame(self, z_ptr, vec_ptr, heads):
         _check(self._L, self._L.trl_mcts_expand_alphasame(self._h, z_ptr, vec_ptr, C.byref(heads)), "trl_mcts_expand_alphasame")
+
+    def mcts_expand_alphasame_masked(self, z_ptr, vec_ptr, heads, mask_ptr, want, last):
+        _check(self._L, self._L.trl_mcts_expand_alphasame_masked(self._h, z_ptr, vec_ptr, C.byref(heads), mask_ptr, int(want), int(last)),
+               "trl_mcts_expand_alphasame_masked")
 
     def mcts_expand(self, values_ptr, policy_ptr):
         _check(self._L, self._L.trl_mcts_expand(self._h, values_ptr, policy_ptr), "trl_mcts_expand")

@@ -40,9 +40,12 @@ def _check_threshold(wins, games, threshold, threshold_type):
 
 class Battle:
     """`games` concurrent games between two evaluators; evaluator k is a callable
-    (grids, vec) -> (values [n], policy [n, 11583]) on the device."""
+    (grids, vec) -> (values [n], policy [n, 11583]) on the device -- or, with `nets=(net_1, net_2)` two AlphaSame
+    nets that run on the fused tower: then a tick is select -> tower of net 1 on its slots' flagged boards -> tower
+    of net 2 on the others -> one expand launch per net (dense heads inside the kernel), one board per leaf as in
+    self-play, instead of both nets' full forward pass over every slot."""
 
-    def __init__(self, config, eval_1, eval_2, games, seed=0, device=0, streams=None):
+    def __init__(self, config, eval_1, eval_2, games, seed=0, device=0, streams=None, nets=None):
         import torch
         self.torch = torch
         self.n = int(games)
@@ -53,18 +56,42 @@ class Battle:
         self.engine.reset(streams)
         self.engine.mcts_create(selfplay.search_options(config, auto_reset=0))
         self.evals = (eval_1, eval_2)
+        self.nets = None
+        if nets is not None and all(getattr(m, "supports_tower_cache", False) and hasattr(m, "device_heads") for m in nets):
+            heads = [m.device_heads() for m in nets]
+            if all(h is not None for h in heads):
+                self.nets, self.heads = tuple(nets), heads
         with torch.cuda.stream(self.stream):
             self.grids = torch.zeros((2, self.n, _eng.GRID_FLOATS), dtype=torch.float32, device=self.device)
             self.vec = torch.zeros((self.n, _eng.VEC_FLOATS), dtype=torch.float32, device=self.device)
             self.side = (torch.arange(self.n, device=self.device) % 2).to(torch.uint8)       # network 1 plays player i % 2
             self.states = torch.as_tensor(_DevView(self.engine.state_dev_ptr(), (self.n, _eng.STATE_BYTES), "|u1"),
                                           device=self.device)
+            if self.nets is not None:
+                self.need = torch.ones(2 * self.n, dtype=torch.uint8, device=self.device)
+                self.z = torch.zeros((2 * self.n, _eng.GRID_FLOATS), dtype=torch.float32, device=self.device)
         self.stream.synchronize()
+
+    def _tick_native(self):
+        torch, e = self.torch, self.engine
+        e.mcts_select_need(self.grids.data_ptr(), self.vec.data_ptr(), self.need.data_ptr())
+        first = (self.states[:, 312] == self.side).to(torch.uint8)       # root side to move is network 1's colour
+        need1 = self.need * first.repeat(2)
+        need2 = self.need - need1
+        self.nets[0].tower_need(self.grids, need1, out=self.z)
+        self.nets[1].tower_need(self.grids, need2, out=self.z)
+        e.mcts_expand_alphasame_masked(self.z.data_ptr(), self.vec.data_ptr(), self.heads[0], first.data_ptr(), 1, 0)
+        e.mcts_expand_alphasame_masked(self.z.data_ptr(), self.vec.data_ptr(), self.heads[1], first.data_ptr(), 0, 1)
+        self._keep = (first, need1, need2)                                # alive until the stream has used them
 
     def tick(self, n=1):
         torch = self.torch
         e = self.engine
         with torch.cuda.stream(self.stream):
+            if self.nets is not None:
+                for _ in range(n):
+                    self._tick_native()
+                return
             for _ in range(n):
                 e.mcts_select(self.grids.data_ptr(), self.vec.data_ptr())
                 first = self.states[:, 312] == self.side               # root side to move is network 1's colour
@@ -113,6 +140,6 @@ def battle_networks(NN_1, config_1, NN_2, config_2, threshold, threshold_type, g
     import torch
     dev = torch.device("cuda", device)
     n1, n2 = NN_1.to(dev).prepare(), NN_2.to(dev).prepare()
-    b = Battle(config_1, n1.evaluate_packed, n2.evaluate_packed, games, seed=seed, device=device)
+    b = Battle(config_1, n1.evaluate_packed, n2.evaluate_packed, games, seed=seed, device=device, nets=(n1, n2))
     wins = b.run()
     return wins, _check_threshold(wins, games, threshold, threshold_type)
