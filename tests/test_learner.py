@@ -51,3 +51,35 @@ def test_one_epoch_matches_reference(golden_dir, tag, tmp_path, monkeypatch):
     assert os.path.isfile(tmp_path / "logs" / "training_log.jsonl")
     # the inference path sees the new weights (folded tensors are rebuilt)
     assert net._folded is None
+
+
+def test_packed_sets_train_exactly_like_the_json_sets(golden_dir, tmp_path, monkeypatch):
+    """load_data_and_train_model over three set files (decay 0.8, shuffled): reading make_training_set's packed form
+    draws the same records in the same order as parsing the JSON, so losses and every weight come out equal"""
+    import json
+    import random
+    import shutil
+    from tetris_rl_amd import records
+    from test_records import _fixture_sets
+    monkeypatch.setenv("TRL_STORAGE", str(tmp_path))
+    mc = nets.AlphaSameConfig(blocks=2, filters=8, dropout=0.0)
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, batch_size=16, shuffle=True, epochs=1,
+                     sets_to_train_with=3, decay_factor=0.8)
+    os.makedirs(cfg.data_dir, exist_ok=True)
+    os.makedirs(learner.packed_dir(cfg), exist_ok=True)
+    for n, (lists, packed) in enumerate(_fixture_sets(golden_dir)):
+        json.dump(lists, open("%s/%d.txt" % (cfg.data_dir, n), "w"))
+        records.PackedSet.from_moves(packed, True).save("%s/%d.npz" % (learner.packed_dir(cfg), n))
+    out = []
+    for use_packed in (True, False):
+        if not use_packed:
+            shutil.rmtree(learner.packed_dir(cfg))
+        torch.manual_seed(3)
+        net = nets.AlphaSame(mc)
+        random.seed(11); torch.manual_seed(5)
+        entry = learner.load_data_and_train_model(cfg, net)
+        out.append((entry, {k: v.clone() for k, v in net.state_dict().items()}))
+    (e1, w1), (e2, w2) = out
+    assert e1["loss"] == e2["loss"] and e1["value_loss"] == e2["value_loss"] and e1["policy_loss"] == e2["policy_loss"]
+    for k in w1:
+        assert torch.equal(w1[k], w2[k]), k

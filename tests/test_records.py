@@ -6,6 +6,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 import oracle_py as op
 from tetris_rl_amd import records
@@ -77,6 +78,49 @@ def test_text_writer_is_byte_identical_to_json_dumps(golden_dir):
         a = records.finish_game([records.records_for_move(st, mv, vis, augment=aug), []], 1, 0, 0.5, 1)
         b = records.finish_game_texts([records.record_texts_for_move(st, mv, vis, augment=aug), []], 1, 0, 0.5, 1)
         assert [json.dumps(r).encode() for r in a] == b
+
+
+def _fixture_sets(golden_dir, augment=True):
+    """the fixture's games as (list-form records, packed moves) per game, z from a made-up winner"""
+    d = np.load(os.path.join(golden_dir, "selfplay.npz"))
+    p_off = np.concatenate([[0], np.cumsum(d["game_plies"])])
+    c_off = np.concatenate([[0], np.cumsum(d["ply_child_counts"])])
+    out = []
+    for gi in range(d["game_ruleset"].shape[0]):
+        gd, gp = [[], []], [[], []]
+        for k in range(p_off[gi], p_off[gi + 1]):
+            st = d["ply_state"][k]
+            mv, vis = d["ply_child_moves"][c_off[k]:c_off[k + 1]], d["ply_child_visits"][c_off[k]:c_off[k + 1]]
+            gd[int(st[312])] += records.records_for_move(st, mv, vis, augment=augment)
+            gp[int(st[312])].append((st, mv, vis))
+        winner = gi % 3 - 1
+        lists = records.finish_game(gd, winner, 0, 0.5, 1)
+        packed = [(s_, m_, v_, 0.5 if winner == -1 else (1 if winner == pl else 0)) for pl in range(2) for s_, m_, v_ in gp[pl]]
+        out.append((lists, packed))
+    return out
+
+
+@pytest.mark.parametrize("augment", [True, False])
+def test_packed_set_expands_to_the_same_tensors(golden_dir, augment, tmp_path):
+    """records.PackedSet (what make_training_set stores for this build's learner) -> the 13 feature arrays, equal
+    element for element and dtype for dtype to torch.tensor over the reference-format records"""
+    import torch
+    sets = _fixture_sets(golden_dir, augment)
+    lists = [r for l, _ in sets for r in l]
+    ps = records.PackedSet.from_moves([p for _, pk in sets for p in pk], augment)
+    ps.save(str(tmp_path / "0.npz"))
+    ps = records.PackedSet.load(str(tmp_path / "0.npz"))
+    assert len(ps) == len(lists)
+    feats = ps.features()
+    ref = list(map(list, zip(*lists)))
+    for i in range(13):
+        a, b = torch.tensor(ref[i]), torch.from_numpy(np.ascontiguousarray(feats[i]))
+        if i == 11:
+            a, b = a.type(torch.float), b.type(torch.float)
+        assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), i
+    sel = np.array([5, 0, len(ps) - 1, 7, 7])
+    for x, y in zip(ps.features(sel), feats):
+        assert np.array_equal(x, y[sel])
 
 
 def test_double_reflection_is_identity(golden_dir):

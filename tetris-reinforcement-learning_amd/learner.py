@@ -7,6 +7,7 @@ import json
 import os
 import random
 
+import numpy as np
 import torch
 from torch import nn
 import torch.nn.functional as F
@@ -85,10 +86,16 @@ def forward_train(net, *features):
 
 # ---- ai.py:1139-1220 -------------------------------------------------------------------------------------------
 def train_network_pytorch(config, model, set, data_number=None, device=None):
+    """`set`: the reference's list of 13-field records, or the 13 feature arrays of records.PackedSet.features()
+    (a tuple) -- the same tensors without the detour through nested Python lists"""
     device = device or next(model.parameters()).device
-    features = list(map(list, zip(*set)))
+    if isinstance(set, tuple):
+        features = [torch.from_numpy(np.ascontiguousarray(f)) for f in set]
+    else:
+        features = list(map(list, zip(*set)))
     for i in range(len(features)):
-        features[i] = torch.tensor(features[i])
+        if not isinstance(features[i], torch.Tensor):
+            features[i] = torch.tensor(features[i])
         if features[i].dim() == 3 and features[i].shape[1] == ROWS and features[i].shape[2] == COLS:
             features[i] = features[i].unsqueeze(dim=1).type(torch.float)
     dataset = torch.utils.data.TensorDataset(*features)
@@ -142,13 +149,52 @@ def get_data_filenames(config):
     return names
 
 
+def packed_dir(config):
+    """where make_training_set puts the packed form of its set files (outside data_dir: the reference lists that)"""
+    return config.data_dir.rstrip("/") + "_packed"
+
+
+def _load_packed(config, names):
+    """the sets `names` as records.PackedSet objects if every one has its packed file, else None"""
+    from . import records
+    out = []
+    for name in names:
+        path = "%s/%s.npz" % (packed_dir(config), name.split(".")[0])
+        if not os.path.isfile(path):
+            return None
+        out.append(records.PackedSet.load(path))
+    return out
+
+
 def load_data_and_train_model(config, model, data=None):
-    """ai.py:1871-1921, 'merge' style: newer sets are sampled fully, older ones with decay_factor ** age"""
+    """ai.py:1871-1921, 'merge' style: newer sets are sampled fully, older ones with decay_factor ** age.
+    When every set has its packed form the records are never materialised as lists: the same random.sample /
+    random.shuffle draws are made over record indices and the feature arrays are built for the chosen records."""
     if config.data_loading_style != "merge":
         raise NotImplementedError
     if data is None:
         data = []
         names = sorted(get_data_filenames(config), key=lambda x: int(x.split(".")[0]), reverse=True)
+        packed = _load_packed(config, names) if names else None
+        if packed is not None:
+            picks = []                                           # (set index, record index) in the reference's order
+            for age, ps in enumerate(packed):
+                n = len(ps)
+                picks.extend((age, j) for j in random.sample(range(n), int(n * config.decay_factor ** age)))
+            if config.shuffle:
+                random.shuffle(picks)
+            parts = {a: ps.features(np.array([j for aa, j in picks if aa == a], dtype=np.int64)) for a, ps in enumerate(packed)}
+            where, counters = np.zeros((len(picks), 2), dtype=np.int64), {a: 0 for a in parts}
+            for k, (a, _) in enumerate(picks):
+                where[k] = (a, counters[a]); counters[a] += 1
+            feats = []
+            for f in range(13):
+                arr = np.empty((len(picks),) + parts[0][f].shape[1:], dtype=parts[0][f].dtype)
+                for a in parts:
+                    sel = where[:, 0] == a
+                    arr[sel] = parts[a][f][where[sel, 1]]
+                feats.append(arr)
+            return train_network_pytorch(config, model, tuple(feats))
         for age, name in enumerate(names):
             with open("%s/%s" % (config.data_dir, name)) as f:
                 s = json.load(f)

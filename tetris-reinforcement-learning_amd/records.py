@@ -304,3 +304,122 @@ def finish_game_texts(game_texts, winner, value_min=0, value_mid=0.5, value_max=
         for h, tl in game_texts[player]:
             out.append(b"[" + h + b", " + zt + b", " + tl + b"]")
     return out
+
+
+# ---- packed sets: the saved moves of a set file, for the learner ---------------------------------------------------
+# The reference's learner parses {n}.txt (hundreds of MB of JSON) and feeds 13 nested Python lists per record to
+# torch.tensor.  make_training_set also writes the same saved moves as a small .npz next to the data directory
+# (320-byte position, root children's moves and visit counts, z); PackedSet.features() expands them to the very same
+# 13 feature arrays, mirror variants included, with numpy -- tests/test_records.py checks them element for element.
+class PackedSet:
+    def __init__(self, states, nchild, moves, visits, z, augment):
+        self.states = np.ascontiguousarray(states, dtype=np.uint8).reshape(-1, 320)
+        self.nchild = np.asarray(nchild, dtype=np.int64)
+        self.moves = np.asarray(moves, dtype=np.uint16).reshape(len(self.nchild), -1)
+        self.visits = np.asarray(visits, dtype=np.uint16).reshape(len(self.nchild), -1)
+        self.z = np.asarray(z, dtype=np.float64)
+        self.augment = bool(augment)
+        self._cache = None
+
+    @classmethod
+    def from_moves(cls, packed_moves, augment):
+        """packed_moves: [(state[320], moves[n], visits[n], z)] in the set file's record order"""
+        m = len(packed_moves)
+        width = max([len(p[1]) for p in packed_moves] + [1])
+        moves, visits = np.zeros((m, width), dtype=np.uint16), np.zeros((m, width), dtype=np.uint16)
+        for i, (_, mv, vis, _) in enumerate(packed_moves):
+            moves[i, :len(mv)] = mv
+            visits[i, :len(vis)] = vis
+        states = np.stack([np.asarray(p[0], dtype=np.uint8) for p in packed_moves]) if m else np.zeros((0, 320), np.uint8)
+        return cls(states, [len(p[1]) for p in packed_moves], moves, visits, [p[3] for p in packed_moves], augment)
+
+    def save(self, path):
+        np.savez_compressed(path, states=self.states, nchild=self.nchild, moves=self.moves, visits=self.visits, z=self.z,
+                            augment=np.array(self.augment))
+
+    @classmethod
+    def load(cls, path):
+        d = np.load(path)
+        return cls(d["states"], d["nchild"], d["moves"], d["visits"], d["z"], bool(d["augment"]))
+
+    def __len__(self):
+        return len(self.nchild) * (4 if self.augment else 1)
+
+    def _per_move(self):
+        """features of every saved move by absolute player: grids [M,2,40,10], pieces [M,2,7,7], scalars [M,2,3], turn"""
+        if self._cache is not None:
+            return self._cache
+        st = self.states
+        m = st.shape[0]
+        grids = np.zeros((m, 2, ROWS, COLS), dtype=np.float32)
+        pieces = np.zeros((m, 2, 2 + PREVIEWS, len(MINOS)), dtype=np.float32)
+        scal = np.zeros((m, 2, 3), dtype=np.int64)
+        ar = np.arange(m)
+        for p, base in enumerate((0, 144)):
+            rows = st[:, base:base + 80].copy().view("<u2").astype(np.uint32)                    # [M, 40]
+            grids[:, p] = ((rows[:, :, None] >> np.arange(COLS, dtype=np.uint32)) & 1).astype(np.float32)
+            queue = st[:, base + 112:base + 120].copy().view("<u8")[:, 0]
+            qlen = np.minimum(st[:, base + 139].astype(np.int64), PREVIEWS)
+            slots = [st[:, base + 137].astype(np.int64), st[:, base + 138].astype(np.int64)]
+            for k in range(PREVIEWS):
+                pc = ((queue >> np.uint64(4 * k)) & np.uint64(15)).astype(np.int64)
+                slots.append(np.where(k < qlen, pc, NO_PIECE))
+            for row, pc in enumerate(slots):
+                ok = pc != NO_PIECE
+                pieces[ar[ok], p, row, pc[ok]] = 1.0
+            scal[:, p, 0] = st[:, base + 132:base + 134].copy().view("<i2")[:, 0]
+            scal[:, p, 1] = st[:, base + 134:base + 136].copy().view("<i2")[:, 0]
+            scal[:, p, 2] = st[:, base + 140]
+        self._cache = (grids, pieces, scal, st[:, 312].astype(np.int64))
+        return self._cache
+
+    def features(self, idx=None):
+        """the 13 feature arrays of records idx (default: all, in file order), as train_network_pytorch builds them
+        from the JSON records: grids float32 [K,40,10], pieces float32 [K,7,7], counters int64 [K], colour int64,
+        z float64, policy float32 [K,27,39,11]"""
+        grids, pieces, scal, turn = self._per_move()
+        n = len(self)
+        idx = np.arange(n) if idx is None else np.asarray(idx, dtype=np.int64)
+        if self.augment:
+            mv, ma, mo = idx // 4, ((idx % 4) // 2).astype(bool), (idx % 2).astype(bool)
+        else:
+            mv, ma, mo = idx, np.zeros(len(idx), bool), np.zeros(len(idx), bool)
+        t = turn[mv]
+        k = np.arange(len(idx))
+        perm = np.arange(len(MINOS))
+        for a_, b_ in _PIECE_MIRROR.items():
+            perm[a_] = b_
+
+        def side(player, mirrored):
+            g = grids[mv, player].copy()
+            g[mirrored] = g[mirrored][:, :, ::-1]
+            p = pieces[mv, player].copy()
+            p[mirrored] = p[mirrored][:, :, perm]            # one-hot column c moves to column mirror(c) (an involution)
+            return g, p, scal[mv, player]
+
+        ag, ap, asc = side(t, ma)
+        og, op, osc = side(1 - t, mo)
+        tt = _tt()
+        pol = np.zeros((len(idx), POLICY_SHAPE[0] * POLICY_SHAPE[1] * POLICY_SHAPE[2]), dtype=np.float32)
+        n_row, n_col = POLICY_SHAPE[1], POLICY_SHAPE[2]
+        cells_of = {}
+        for j in range(len(idx)):
+            i = int(mv[j])
+            if i not in cells_of:
+                nc = int(self.nchild[i])
+                total = int(self.visits[i, :nc].astype(np.int64).sum())
+                cells = {}
+                for m_, v_ in zip(self.moves[i, :nc].tolist(), self.visits[i, :nc].tolist()):
+                    if v_ != 0:
+                        cells[(((m_ >> 10) & 31) * n_row + ((m_ >> 4) & 63)) * n_col + (m_ & 15)] = round(v_ / total, 4)
+                keys = np.fromiter(cells.keys(), dtype=np.int64, count=len(cells))
+                vals = np.fromiter(cells.values(), dtype=np.float64, count=len(cells))
+                pos = vals > 0
+                cells_of[i] = (keys, vals, tt.mirror[keys[pos]], vals[pos])
+            keys, vals, mkeys, mvals = cells_of[i]
+            if ma[j]:
+                pol[j, mkeys] = mvals
+            else:
+                pol[j, keys] = vals
+        return [ag, ap, asc[:, 0], asc[:, 1], asc[:, 2], og, op, osc[:, 0], osc[:, 1], osc[:, 2], t.copy(),
+                self.z[mv], pol.reshape((len(idx),) + POLICY_SHAPE)]

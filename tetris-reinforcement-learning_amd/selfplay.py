@@ -239,19 +239,23 @@ class GameCollector:
                 self.open.setdefault(key, []).append(r.copy())
             else:
                 moves = sorted(self.open.pop(key, []), key=lambda x: int(x["ply"]))
-                game_data = [[], []]
+                game_data, saved = [[], []], [[], []]
                 per_move = records.record_texts_for_move if self.as_text else records.records_for_move
                 for m in moves:
                     if m["saved"]:
                         n = int(m["n_children"])
                         game_data[int(m["state"][312])] += per_move(m["state"], m["moves"][:n], m["visits"][:n],
                                                                     augment=self.config.augment_data)
+                        saved[int(m["state"][312])].append((m["state"].copy(), m["moves"][:n].copy(), m["visits"][:n].copy()))
                 c = self.config
                 finish = records.finish_game_texts if self.as_text else records.finish_game
                 data = finish(game_data, int(r["winner"]), c.value_min, c.value_mid, c.value_max)
                 p0 = records.unpack_player(r["state"][0:144])
                 stats = {"app": p0["lines_sent"] / max(p0["pieces"], 1), "dspp": p0["lines_cleared"] / max(p0["pieces"], 1)}
-                self.finished.append(dict(key=key, data=data, stats=stats, plies=int(r["ply"]), winner=int(r["winner"]),
+                w = int(r["winner"])
+                packed = [(st, mv, vis, c.value_mid if w == -1 else (c.value_max if w == pl else c.value_min))
+                          for pl in range(2) for st, mv, vis in saved[pl]]          # the set file's record order
+                self.finished.append(dict(key=key, data=data, packed=packed, stats=stats, plies=int(r["ply"]), winner=int(r["winner"]),
                                           moves=[int(m["chosen"]) for m in moves]))
 
 
@@ -414,6 +418,11 @@ def make_training_set(config, interference_network, num_games, save_game=False, 
         else:
             with open("%s/%d.txt" % (config.data_dir, next_set), "w") as f:
                 f.write(json.dumps(series_data))
+        # the same saved moves in packed form for this build's learner (records.PackedSet; learner.packed_dir)
+        from . import learner
+        os.makedirs(learner.packed_dir(config), exist_ok=True)
+        records.PackedSet.from_moves([p for g in games for p in g["packed"]], config.augment_data).save(
+            "%s/%d.npz" % (learner.packed_dir(config), next_set))
     if save_stats:
         logs = storage_root() / "logs"
         logs.mkdir(parents=True, exist_ok=True)
