@@ -134,16 +134,28 @@ int trl_engine_create(const trl_config *cfg, trl_engine **out) {
     if (!h) return fail(TRL_E_INVALID, "trl_engine_create: %s", "out of host memory");
     memset(h, 0, sizeof *h);
     h->cfg = *cfg;
-    if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; h->own_stream = false; }
-    else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
-    size_t n = (size_t)cfg->n_games;
-    HIPCHK(hipMalloc(&h->d_states, n * sizeof(trl_game_state)));
-    HIPCHK(hipMalloc(&h->d_counts, n * sizeof(uint16_t)));
-    HIPCHK(hipMalloc(&h->d_moves, n * TRL_MAX_LEGAL * sizeof(uint16_t)));
-    HIPCHK(hipMalloc(&h->d_in_moves, n * sizeof(uint16_t)));
-    HIPCHK(hipMalloc(&h->d_steps, sizeof(unsigned long long)));
-    HIPCHK(hipEventCreate(&h->ev0));
-    HIPCHK(hipEventCreate(&h->ev1));
+    auto alloc = [&]() -> int {
+        if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; h->own_stream = false; }
+        else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+        size_t n = (size_t)cfg->n_games;
+        HIPCHK(hipMalloc(&h->d_states, n * sizeof(trl_game_state)));
+        HIPCHK(hipMalloc(&h->d_counts, n * sizeof(uint16_t)));
+        HIPCHK(hipMalloc(&h->d_moves, n * TRL_MAX_LEGAL * sizeof(uint16_t)));
+        HIPCHK(hipMalloc(&h->d_in_moves, n * sizeof(uint16_t)));
+        HIPCHK(hipMalloc(&h->d_steps, sizeof(unsigned long long)));
+        HIPCHK(hipEventCreate(&h->ev0));
+        HIPCHK(hipEventCreate(&h->ev1));
+        return TRL_OK;
+    };
+    int rc = alloc();
+    if (rc != TRL_OK) {                            // release what was allocated before the failure
+        hipFree(h->d_states); hipFree(h->d_counts); hipFree(h->d_moves); hipFree(h->d_in_moves); hipFree(h->d_steps);
+        if (h->ev0) hipEventDestroy(h->ev0);
+        if (h->ev1) hipEventDestroy(h->ev1);
+        if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+        delete h;
+        return rc;
+    }
     *out = h;
     return TRL_OK;
 }

@@ -819,6 +819,33 @@ void trl_mcts_free_internal(trl_engine *h) {
     h->mcts = nullptr;
 }
 
+static int mcts_alloc(trl_engine *h, trl_mcts *m) {
+    DevMcts &d = m->d;
+    size_t nn = (size_t)d.n_games * d.max_nodes, n = (size_t)d.n_games;
+    HIPCHK(hipMalloc(&d.t.parent, nn * 4)); HIPCHK(hipMalloc(&d.t.first, nn * 4)); HIPCHK(hipMalloc(&d.t.visit, nn * 4));
+    HIPCHK(hipMalloc(&d.t.state, nn * 4)); HIPCHK(hipMalloc(&d.t.nchild, nn * 2)); HIPCHK(hipMalloc(&d.t.move, nn * 2));
+    HIPCHK(hipMalloc(&d.t.wsum, nn * 8)); HIPCHK(hipMalloc(&d.t.q, nn * 8)); HIPCHK(hipMalloc(&d.t.prior, nn * 8));
+    HIPCHK(hipMalloc(&d.t.pf32, nn)); HIPCHK(hipMalloc(&d.t.turn, nn));
+    HIPCHK(hipMalloc(&d.ctl, n * sizeof(SlotCtl)));
+    HIPCHK(hipMalloc(&d.pool, n * d.cap_states * sizeof(trl_game_state)));
+    HIPCHK(hipMalloc(&d.leaf_moves, n * TRL_MAX_LEGAL * 2));
+    HIPCHK(hipMalloc(&d.path, n * PATH_CAP * sizeof(int32_t)));
+    d.zdim = 400;
+    HIPCHK(hipMalloc(&d.zcache, n * d.cap_states * 2 * d.zdim * sizeof(float)));
+    HIPCHK(hipMalloc(&d.recs, (size_t)d.rec_cap * sizeof(trl_record)));
+    HIPCHK(hipMalloc(&d.rec_count, 4));
+    HIPCHK(hipMalloc(&d.counters, 8 * 8));
+    HIPCHK(hipMalloc(&m->d_leaf_tmp, n * sizeof(trl_game_state)));
+    HIPCHK(hipMalloc(&m->d_info_tmp, n * 16));
+    HIPCHK(hipMalloc(&m->d_root_tmp, n * (4 + TRL_MAX_LEGAL * (2 + 4 + 8 + 8))));
+    HIPCHK(hipMemsetAsync(d.ctl, 0, n * sizeof(SlotCtl), h->stream));            // phase 0: start a search
+    HIPCHK(hipMemsetAsync(d.t.nchild, 0, nn * 2, h->stream));
+    HIPCHK(hipMemsetAsync(d.rec_count, 0, 4, h->stream));
+    HIPCHK(hipMemsetAsync(d.counters, 0, 64, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return TRL_OK;
+}
+
 extern "C" {
 
 int trl_mcts_create(trl_engine *h, const trl_mcts_config *cfg) {
@@ -844,29 +871,9 @@ int trl_mcts_create(trl_engine *h, const trl_mcts_config *cfg) {
     // default tree capacity: one expansion per simulation, ~50 children each (measured: 20.5 k nodes after 400
     // simulations), with headroom; never below 65 536
     d.max_nodes = cfg->max_nodes > 0 ? cfg->max_nodes : (longest * 96 > DEFAULT_MAX_NODES ? longest * 96 : DEFAULT_MAX_NODES);
-    size_t nn = (size_t)d.n_games * d.max_nodes, n = (size_t)d.n_games;
-    HIPCHK(hipMalloc(&d.t.parent, nn * 4)); HIPCHK(hipMalloc(&d.t.first, nn * 4)); HIPCHK(hipMalloc(&d.t.visit, nn * 4));
-    HIPCHK(hipMalloc(&d.t.state, nn * 4)); HIPCHK(hipMalloc(&d.t.nchild, nn * 2)); HIPCHK(hipMalloc(&d.t.move, nn * 2));
-    HIPCHK(hipMalloc(&d.t.wsum, nn * 8)); HIPCHK(hipMalloc(&d.t.q, nn * 8)); HIPCHK(hipMalloc(&d.t.prior, nn * 8));
-    HIPCHK(hipMalloc(&d.t.pf32, nn)); HIPCHK(hipMalloc(&d.t.turn, nn));
-    HIPCHK(hipMalloc(&d.ctl, n * sizeof(SlotCtl)));
-    HIPCHK(hipMalloc(&d.pool, n * d.cap_states * sizeof(trl_game_state)));
-    HIPCHK(hipMalloc(&d.leaf_moves, n * TRL_MAX_LEGAL * 2));
-    HIPCHK(hipMalloc(&d.path, n * PATH_CAP * sizeof(int32_t)));
-    d.zdim = 400;
-    HIPCHK(hipMalloc(&d.zcache, n * d.cap_states * 2 * d.zdim * sizeof(float)));
-    HIPCHK(hipMalloc(&d.recs, (size_t)d.rec_cap * sizeof(trl_record)));
-    HIPCHK(hipMalloc(&d.rec_count, 4));
-    HIPCHK(hipMalloc(&d.counters, 8 * 8));
-    HIPCHK(hipMalloc(&m->d_leaf_tmp, n * sizeof(trl_game_state)));
-    HIPCHK(hipMalloc(&m->d_info_tmp, n * 16));
-    HIPCHK(hipMalloc(&m->d_root_tmp, n * (4 + TRL_MAX_LEGAL * (2 + 4 + 8 + 8))));
-    HIPCHK(hipMemsetAsync(d.ctl, 0, n * sizeof(SlotCtl), h->stream));            // phase 0: start a search
-    HIPCHK(hipMemsetAsync(d.t.nchild, 0, nn * 2, h->stream));
-    HIPCHK(hipMemsetAsync(d.rec_count, 0, 4, h->stream));
-    HIPCHK(hipMemsetAsync(d.counters, 0, 64, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    h->mcts = m;
+    h->mcts = m;                                   // owned by the engine from here on: a failed allocation below
+    int rc = mcts_alloc(h, m);                     // (a tree larger than the free HBM) is released, not leaked
+    if (rc != TRL_OK) { trl_mcts_free_internal(h); return rc; }
     return TRL_OK;
 }
 
