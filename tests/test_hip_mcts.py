@@ -245,3 +245,16 @@ def test_c5_search_shape_matches_oracle():
             assert nc == o["ply_nchild"][i]
             assert np.array_equal(mine["moves"][i][:nc], o["child_moves"][off[i]:off[i + 1]])
             assert np.array_equal(mine["visits"][i][:nc], o["child_visits"][off[i]:off[i + 1]])
+
+
+def test_oversized_tree_is_refused_cleanly():
+    """a tree that cannot fit in HBM: trl_mcts_create fails with an error (no crash, no leak of the partial
+    allocations) and the engine takes a normal search afterwards"""
+    eng = trl.Engine(64, ruleset="s2", seed=1)
+    eng.reset()
+    with pytest.raises(trl.EngineError):
+        eng.mcts_create(trl.mcts_config(max_iter=16, max_nodes=2_000_000_000))
+    s = StubSearch(eng, trl.mcts_config(max_iter=16, training=0, auto_reset=0))
+    for _ in range(40):
+        s.tick()
+    assert eng.mcts_stats()["simulations"] == 40 * 64

@@ -99,6 +99,7 @@ inline int fail(int code, const char *fmt, const char *detail) {
 #define HIPCHK(call)                                                        \
     do {                                                                    \
         hipError_t e_ = (call);                                             \
-        if (e_ != hipSuccess) return fail(TRL_E_HIP, #call ": %s", hipGetErrorString(e_)); \
+        if (e_ != hipSuccess) { (void)hipGetLastError(); /* reported here: do not leave it for the next HIP user */ \
+                                return fail(TRL_E_HIP, #call ": %s", hipGetErrorString(e_)); } \
     } while (0)
 
