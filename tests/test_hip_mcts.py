@@ -258,3 +258,17 @@ def test_oversized_tree_is_refused_cleanly():
     for _ in range(40):
         s.tick()
     assert eng.mcts_stats()["simulations"] == 40 * 64
+
+
+def test_record_buffer_overflow_is_counted_not_silent():
+    """more finished searches than the device record buffer holds between drains: the surplus is counted in
+    stats.records_dropped (the drivers turn that into an error), nothing is overwritten"""
+    eng = trl.Engine(64, ruleset="s2", seed=3)
+    eng.reset()
+    s = StubSearch(eng, trl.mcts_config(max_iter=8, training=0, auto_reset=0, record_capacity=16))
+    for _ in range(8):
+        s.tick()
+    st = eng.mcts_stats()
+    recs = eng.mcts_drain_records()
+    assert st["moves"] == 64 and len(recs) == 16 and st["records_dropped"] == 64 - 16
+    assert len(set(recs["slot"].tolist())) == 16
