@@ -261,8 +261,9 @@ class GameCollector:
 
 # ---- model / data numbering (ai.py:2306-2355) ------------------------------------------------------------------
 def _highest_number(path, strip=None):
-    os.makedirs(path, exist_ok=True)
     best = -1
+    if not os.path.isdir(path):              # nothing stored yet; reading a number must not need a writable Storage/
+        return best
     for name in os.listdir(path):
         stem = name[:-len(strip)] if (strip and name.endswith(strip)) else name.split(".")[0]
         if stem.isdigit():
@@ -408,6 +409,7 @@ def make_training_set(config, interference_network, num_games, save_game=False, 
         series_data.extend(g["data"])
         series_stats.append(g["stats"])
     if save_game:
+        os.makedirs(config.data_dir, exist_ok=True)
         next_set = highest_data_number(config) + 1
         if as_text:
             with open("%s/%d.txt" % (config.data_dir, next_set), "wb") as f:
