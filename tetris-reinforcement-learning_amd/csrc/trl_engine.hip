@@ -65,14 +65,29 @@ __global__ __launch_bounds__(BLOCK) void k_step(trl_game_state *states, const ui
 }
 
 // C2 workload: n_plies x { legal -> uniform pick -> make_move(add_bag) -> re-setup when finished }
+// Pacing: every game plays its plies in sequence, so the launch ends with the slot whose games were the most expensive.
+// Slots publish their progress (one atomic per 8 plies) and a slot that has fallen behind the mean raises its waves'
+// issue priority over the co-resident slots that are ahead -- the stragglers catch up while the CU is still full
+// instead of finishing alone at single-wave speed.  Scheduling only: the games are the same.
 __global__ __launch_bounds__(BLOCK, 8) void k_rollout(trl_game_state *states, uint64_t seed, int n_plies, int max_plies,
                                                    unsigned long long *steps_total) {
     __shared__ BlockShared sh;
     const int tid = threadIdx.x, game = blockIdx.x;
+    unsigned long long *progress = steps_total ? steps_total + 1 : nullptr;
     load_state(sh, states + game, tid);
+    if (tid == 0) sh.done = 0;
     __syncthreads();
     int steps = 0;
     for (int k = 0; k < n_plies; k++) {
+        if (progress && (k & 7) == 0) {
+            if (tid == 0) {
+                if (k) atomicAdd(progress, 8ull);
+                const unsigned long long tot = __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh.done = ((unsigned long long)(k + 6) * gridDim.x < tot) ? 1 : 0;     // more than 6 plies behind the mean
+            }
+            __syncthreads();
+            if (sh.done) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+        }
         int total = block_movegen(sh, tid);
         if (tid < 64) {
             trl_game_state &g = sh.g;
@@ -142,7 +157,7 @@ int trl_engine_create(const trl_config *cfg, trl_engine **out) {
         HIPCHK(hipMalloc(&h->d_counts, n * sizeof(uint16_t)));
         HIPCHK(hipMalloc(&h->d_moves, n * TRL_MAX_LEGAL * sizeof(uint16_t)));
         HIPCHK(hipMalloc(&h->d_in_moves, n * sizeof(uint16_t)));
-        HIPCHK(hipMalloc(&h->d_steps, sizeof(unsigned long long)));
+        HIPCHK(hipMalloc(&h->d_steps, 2 * sizeof(unsigned long long)));       // [0] steps, [1] pacing counter
         HIPCHK(hipEventCreate(&h->ev0));
         HIPCHK(hipEventCreate(&h->ev1));
         return TRL_OK;
@@ -301,7 +316,7 @@ int trl_env_rollout_random(trl_engine *h, int n_plies, int max_plies, uint64_t *
     if (!h || n_plies < 0 || max_plies <= 0) return fail(TRL_E_INVALID, "%s", "bad argument");
     if (!h->have_reset) return fail(TRL_E_STATE, "%s", "trl_env_rollout_random before trl_env_reset / trl_env_set_state");
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(hipMemsetAsync(h->d_steps, 0, sizeof(unsigned long long), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_steps, 0, 2 * sizeof(unsigned long long), h->stream));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(k_rollout, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->d_states, h->cfg.seed,
                        n_plies, max_plies, h->d_steps);
