@@ -66,22 +66,23 @@ __global__ __launch_bounds__(BLOCK) void k_step(trl_game_state *states, const ui
 
 // C2 workload: n_plies x { legal -> uniform pick -> make_move(add_bag) -> re-setup when finished }
 // Pacing: every game plays its plies in sequence, so the launch ends with the slot whose games were the most expensive.
-// Slots publish their progress (one atomic per 8 plies) and a slot that has fallen behind the mean raises its waves'
+// Slots publish their progress (one atomic per 16 plies) and a slot that has fallen behind the mean raises its waves'
 // issue priority over the co-resident slots that are ahead -- the stragglers catch up while the CU is still full
-// instead of finishing alone at single-wave speed.  Scheduling only: the games are the same.
+// instead of finishing alone at single-wave speed.  Scheduling only: the games are the same.  (Only when all slots
+// are resident at once: with more slots than residency the hardware refills the CUs and late starters are not behind.)
 __global__ __launch_bounds__(BLOCK, 8) void k_rollout(trl_game_state *states, uint64_t seed, int n_plies, int max_plies,
-                                                   unsigned long long *steps_total) {
+                                                   unsigned long long *steps_total, int pacing) {
     __shared__ BlockShared sh;
     const int tid = threadIdx.x, game = blockIdx.x;
-    unsigned long long *progress = steps_total ? steps_total + 1 : nullptr;
+    unsigned long long *progress = (steps_total && pacing) ? steps_total + 1 : nullptr;
     load_state(sh, states + game, tid);
     if (tid == 0) sh.done = 0;
     __syncthreads();
     int steps = 0;
     for (int k = 0; k < n_plies; k++) {
-        if (progress && (k & 7) == 0) {
+        if (progress && (k & 15) == 0) {
             if (tid == 0) {
-                if (k) atomicAdd(progress, 8ull);
+                if (k) atomicAdd(progress, 16ull);
                 const unsigned long long tot = __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 sh.done = ((unsigned long long)(k + 6) * gridDim.x < tot) ? 1 : 0;     // more than 6 plies behind the mean
             }
@@ -318,8 +319,11 @@ int trl_env_rollout_random(trl_engine *h, int n_plies, int max_plies, uint64_t *
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipMemsetAsync(h->d_steps, 0, 2 * sizeof(unsigned long long), h->stream));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, h->cfg.device));
+    const int pacing = h->cfg.n_games <= 16 * prop.multiProcessorCount;     // 16 workgroups of this kernel fit a CU
     hipLaunchKernelGGL(k_rollout, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->d_states, h->cfg.seed,
-                       n_plies, max_plies, h->d_steps);
+                       n_plies, max_plies, h->d_steps, pacing);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     if (steps_out) {
