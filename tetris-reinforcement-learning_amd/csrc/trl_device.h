@@ -228,20 +228,20 @@ static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int typ
             //     this item does not change, so they are deferred until the whole flood is known.
             uint32_t r = 1u << fmx;
             int nrows = 0;
-            for (int fy = fmy; fy < MAP_H && r; ++fy, ++nrows) {
-                uint32_t vr = S.valid[frot][fy];
-                uint32_t unvis = vr & ~(uint32_t)S.visited[frot][fy];
-                r = row_fill(unvis, r);
-                uint32_t next_vr = (fy + 1 < MAP_H) ? (uint32_t)S.valid[frot][fy + 1] : 0u;
-                uint32_t next_vis = (fy + 1 < MAP_H) ? (uint32_t)S.visited[frot][fy + 1] : 0u;
-                uint32_t blocked_down = r & ~next_vr;
-                uint32_t edges = blocked_down | (r & ~(vr << 1)) | (r & ~(vr >> 1));
+            uint32_t vr = S.valid[frot][fmy], rvis = S.visited[frot][fmy];      // the row below becomes the next row:
+            for (int fy = fmy; fy < MAP_H && r; ++fy, ++nrows) {                    // two LDS reads per row, not four
+                r = row_fill(vr & ~rvis, r);
+                const uint32_t next_vr = (fy + 1 < MAP_H) ? (uint32_t)S.valid[frot][fy + 1] : 0u;
+                const uint32_t next_vis = (fy + 1 < MAP_H) ? (uint32_t)S.visited[frot][fy + 1] : 0u;
+                const uint32_t blocked_down = r & ~next_vr;
+                const uint32_t edges = blocked_down | (r & ~(vr << 1)) | (r & ~(vr >> 1));
                 if (lane == 0) {
-                    S.visited[frot][fy] |= (uint16_t)r;
+                    S.visited[frot][fy] = (uint16_t)(rvis | r);
                     S.present[frot][fy] |= (uint16_t)blocked_down;                     // :439-440
                     S.edge[nrows] = (uint16_t)edges;
                 }
                 r = r & next_vr & ~next_vis;
+                vr = next_vr; rvis = next_vis;
             }
             wave_sync();
             PROF_T(q2); PROF_ADD(2, q1, q2); PROF_ADD(9, 0ull, (unsigned long long)nrows);
