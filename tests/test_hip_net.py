@@ -115,6 +115,20 @@ def test_self_play_loop_generates_trains_and_gates(tmp_path, monkeypatch):
     assert trl.highest_model_number(cfg) == sum(1 for g in gl if g["accepted"])
 
 
+def test_self_play_loop_with_the_default_net_family(tmp_path, monkeypatch):
+    """the outer loop with an AuxBaseResNetConfig: the net class follows the model_config as in the reference
+    (ai.py:1048-1053), self-play runs on the fused 32-filter tower, the learner adds the auxiliary loss"""
+    monkeypatch.setenv("TRL_STORAGE", str(tmp_path / "Storage"))
+    mc = trl.AuxBaseResNetConfig(blocks=2, filters=32, opp_hidden=16, own_kernels=4, value_hidden=8, aux_hidden=8)
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=8, training=False, training_games=3,
+                     battle_games=4, sets_to_train_with=2, batch_size=16)
+    assert trl.self_play_loop(cfg, max_sets=1, seed=2) == 1
+    best = trl.load_best_model(cfg)
+    assert type(best).__name__ == "AuxBaseResNet" and trl.highest_data_number(cfg) == 0
+    log = [__import__("json").loads(l) for l in open(tmp_path / "Storage" / "logs" / "training_log.jsonl")]
+    assert len(log) == 1 and "aux_loss" in log[0]
+
+
 def test_fused_hip_tower_matches_torch_tower(golden_dir):
     """csrc/trl_net.hip (fp32 MFMA, activations in LDS) against the same tower as PyTorch ops, on
     random occupancy boards incl. full, empty and checkerboard ones; fp32 tolerance 2e-5 absolute on

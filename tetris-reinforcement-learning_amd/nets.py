@@ -258,9 +258,19 @@ class AlphaSame(nn.Module):
         return v.reshape(n, 1), logits
 
 
+def model_for_config(model_config=None, use_tanh=False):
+    """the net class the reference instantiates for a model_config (ai.py:1048-1053): AuxBaseResNetConfig ->
+    AuxBaseResNet, BaseResNetConfig -> BaseResNet, anything else (AlphaSameConfig) -> AlphaSame"""
+    if isinstance(model_config, AuxBaseResNetConfig):
+        return AuxBaseResNet(model_config, use_tanh)
+    if isinstance(model_config, BaseResNetConfig):
+        return BaseResNet(model_config, use_tanh)
+    return AlphaSame(model_config, use_tanh)
+
+
 def load_reference_checkpoint(path, model_config=None, device="cpu"):
     """`torch.save(model.state_dict(), '{n}.pt')` files of the reference (ai.py:1082, 2192)"""
-    net = AlphaSame(model_config)
+    net = model_for_config(model_config)
     sd = torch.load(path, map_location="cpu", weights_only=True)
     net.load_state_dict(sd)
     return net.to(device).prepare()

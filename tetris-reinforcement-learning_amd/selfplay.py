@@ -280,9 +280,9 @@ def highest_data_number(config):
 
 
 def instantiate_network(config, nn_generator=None, show_summary=False, save_network=True):
-    """ai.py:1033-1085 for the PyTorch AlphaSame family: random-init net, saved as {n}.pt"""
+    """ai.py:1033-1085, PyTorch branch: random-init net of the class the model_config names, saved as {n}.pt"""
     import torch
-    net = (nn_generator or nets.AlphaSame)(config.model_config)
+    net = nn_generator(config.model_config) if nn_generator else nets.model_for_config(config.model_config)
     if save_network:
         os.makedirs(config.model_dir, exist_ok=True)
         torch.save(net.state_dict(), "%s/%d.pt" % (config.model_dir, highest_model_number(config) + 1))
