@@ -12,6 +12,8 @@ def test_defaults_match_reference_config():
     assert (c.use_root_softmax, c.RootSoftmaxTemp, c.temperature) == (True, 1.1, 0.1)
     assert (c.playout_cap_chance, c.playout_cap_mult, c.DIRICHLET_ALPHA, c.DIRICHLET_S, c.DIRICHLET_EXPLORATION) == (0.25, 5, 0.1, 25, 0.25)
     assert c.ruleset == "s2" and c.move_algorithm == "convolutional" and c.augment_data and not c.save_all
+    assert type(c.model_config).__name__ == "AuxBaseResNetConfig"                       # ai.py:83
+    assert (c.model_config.blocks, c.model_config.filters, c.model_config.own_kernels) == (8, 32, 4)
     assert (c.value_min, c.value_mid, c.value_max) == (0, 0.5, 1) and c.negate_value(0.25) == 0.75
     t = trl.Config(use_tanh=True)
     assert (t.value_min, t.value_mid, t.value_max) == (-1, 0, 1) and t.negate_value(0.25) == -0.25

@@ -51,7 +51,7 @@ class Config:
         for k, v in _CONFIG_DEFAULTS.items():
             setattr(self, k, kwargs.get(k, list(v) if isinstance(v, list) else v))
         if self.model_config is None:
-            self.model_config = nets.AlphaSameConfig()
+            self.model_config = nets.AuxBaseResNetConfig()          # the reference's default (ai.py:83)
 
     def copy(self):
         return Config(**{k: getattr(self, k) for k in _CONFIG_DEFAULTS})
