@@ -272,3 +272,38 @@ def test_record_buffer_overflow_is_counted_not_silent():
     recs = eng.mcts_drain_records()
     assert st["moves"] == 64 and len(recs) == 16 and st["records_dropped"] == 64 - 16
     assert len(set(recs["slot"].tolist())) == 16
+
+
+def test_auto_reset_episodes_match_oracle_games():
+    """auto_reset=1 (more games than slots, as make_training_set plays them): when a game ends its slot is set up
+    again on RNG stream + 2^24; every (slot, episode) game equals the oracle's play_game on that stream"""
+    n, seed = 6, 909
+    cfgk = dict(max_iter=16, training=1)
+    eng = trl.Engine(n, ruleset="s2", seed=seed)
+    eng.reset()
+    s = StubSearch(eng, trl.mcts_config(auto_reset=1, **cfgk))
+    chunks, ends = [], 0
+    for t in range(200000):
+        s.tick()
+        if t % 256 == 255:
+            r = eng.mcts_drain_records()
+            chunks.append(r)
+            ends += int((r["kind"] == trl.REC_GAME_END).sum())
+            if ends >= 3 * n + 6:
+                break
+    recs = np.concatenate(chunks)
+    assert eng.mcts_stats()["overflow"] == 0
+    checked = 0
+    for slot in range(n):
+        for ep in range(3):
+            mine = recs[(recs["slot"] == slot) & (recs["episode"] == ep)]
+            end = mine[mine["kind"] == trl.REC_GAME_END]
+            if len(end) == 0:
+                continue
+            mv = mine[mine["kind"] == trl.REC_MOVE]
+            mv = mv[np.argsort(mv["ply"], kind="stable")]
+            o = op.play_game_stub(2, seed, slot + (ep << 24), op.default_mcts_config(**cfgk))
+            assert len(mv) == o["plies"] and np.array_equal(mv["chosen"], o["ply_move"]), (slot, ep)
+            assert int(end[0]["winner"]) == o["winner"]
+            checked += 1
+    assert checked >= 2 * n
