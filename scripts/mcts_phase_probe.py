@@ -22,5 +22,6 @@ L.trl_debug_mcts_prof(buf, 1)
 v = np.array(buf[:], dtype=np.float64) / (T * n)
 print("k_select, cycles per slot-tick: ctl+new search %.0f | selection walk %.0f | make_move %.0f | legal moves %.0f | features+ctl %.0f | total %.0f"
       % (v[0], v[1], v[2], v[3], v[4], v[:5].sum()))
+print("   of which legal-move logits %.0f | normalisation + child initialisation %.0f" % (v[13], v[14]))
 print("k_expand<2>: z+dense heads %.0f | policy logits+children %.0f | noise %.0f | backup+fpu %.0f | end of search %.0f | ctl store %.0f | total %.0f"
       % (v[8], v[9], v[10], v[11], v[12], 0, v[8:13].sum()))

@@ -504,6 +504,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
                 mymax = fmaxf(mymax, p);
             }
         }
+        MPROF_T(mex1); MPROF_ADD(13, me1, mex1);                              // legal-move logits
         const bool root_soft = (leaf == 0) && cfg.use_root_softmax;
         if (root_soft) {                                                       // ai.py:428-434
 #pragma unroll
@@ -530,6 +531,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
             if (root_soft) { M.t.prior[ci] = sh.pd[k] / dsum; M.t.pf32[ci] = 0; }
             else { M.t.prior[ci] = (double)(sh.pf[k] / fsum); M.t.pf32[ci] = 1; }
         }
+        MPROF_T(mex2); MPROF_ADD(14, mex1, mex2);                             // normalisation + child initialisation
         if (tid == 0 && n > 0) {
             M.t.first[nb + leaf] = first; M.t.nchild[nb + leaf] = (uint16_t)n;
             sh.ctl.n_nodes = first + n;
