@@ -127,14 +127,16 @@ __device__ __forceinline__ uint32_t row_fill(uint32_t m, uint32_t seed) {
 // emitter of my key" is settled in registers (one readlane per emitter), then every deciding lane updates the
 // planes at once with LDS atomics on the 32-bit words holding the 16-bit row masks.
 __device__ __forceinline__ void emit_flagged(MgScratch &S, bool emit, int rot, int my, uint32_t bit, int ul, int lane, bool isT) {
+    // Only the T planes look at the flags.  For the other pieces a flagged placement is one more way to reach a cell
+    // that is stuck and visited -- and every visited stuck cell got its `present` bit from the flood that visited it
+    // (blocked_down), so the flag adds nothing to present | flagged (move_generation.py:650-749 merges them).
+    if (!isT) return;
     uint64_t m = __ballot(emit);
     if (!m) return;
     const int idx = rot * MAP_H + my;
     const uint32_t wbit = bit << ((idx & 1) * 16);
     unsigned int *fw = reinterpret_cast<unsigned int *>(&S.flagp[0][0]) + (idx >> 1);
-    if (!isT) {                                   // only T planes look at the flags: any order
-        if (emit) atomicOr(fw, wbit);
-    } else {
+    {
         const int key = (idx << 4) | (31 - __clz((int)bit));
         bool last = emit;
         for (uint64_t mm = m; mm; mm &= mm - 1) {
