@@ -178,7 +178,8 @@ static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int typ
     for (int i = lane; i < 4 * MAP_H; i += 64) {
         int r = i / MAP_H, ym = i - r * MAP_H;
         S.valid[r][ym] = (uint16_t)valid_row(rows, type, r, ym);
-        S.visited[r][ym] = 0; S.present[r][ym] = 0; S.flagp[r][ym] = 0; S.ulp[r][ym] = 0;
+        S.visited[r][ym] = 0; S.present[r][ym] = 0;
+        if (type == PT) { S.flagp[r][ym] = 0; S.ulp[r][ym] = 0; }                // only T reads the flag planes
     }
     // _get_highest_row / _set_starting_position (move_generation.py:164-180)
     uint64_t occ = __ballot(lane < TRL_ROWS && rows[lane < TRL_ROWS ? lane : 0] != 0);
@@ -210,13 +211,16 @@ static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int typ
             uint32_t it = S.queue[act ? idx : head];
             int mx = it & 15, my = (it >> 4) & 63, rot = (it >> 10) & 3, fl = (it >> 12) & 1, ul = (it >> 13) & 1;
             uint32_t bit = 1u << mx;
-            const uint32_t cv = S.visited[rot][my], cb = S.valid[rot][my + 1 < MAP_H ? my + 1 : my];
+            const uint32_t cv = S.visited[rot][my];
             bool vis = act & ((cv & bit) != 0);
-            bool stuck = (my + 1 >= MAP_H) | ((cb & bit) == 0);
             uint64_t unv = __ballot(act && !vis);
             int first = unv ? (__ffsll((unsigned long long)unv) - 1) : 64;
-            // items up to and including the first unvisited one are popped now (:382-398)
-            emit_flagged(S, act & (lane <= first) & (fl != 0) & stuck, rot, my, bit, ul, lane, type == PT);
+            // items up to and including the first unvisited one are popped now (:382-398); only T keeps their flags
+            if (type == PT) {
+                const uint32_t cb = S.valid[rot][my + 1 < MAP_H ? my + 1 : my];
+                const bool stuck = (my + 1 >= MAP_H) | ((cb & bit) == 0);
+                emit_flagged(S, act & (lane <= first) & (fl != 0) & stuck, rot, my, bit, ul, lane, true);
+            }
             PROF_T(q1); PROF_ADD(1, q0, q1); PROF_ADD(8, 0ull, 1ull);
             if (first == 64) { int n = tail - head; head += (n < 64 ? n : 64); continue; }
             head += first + 1;
@@ -299,9 +303,8 @@ static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int typ
                 const bool found = found_i != 0;
                 int nul = (isT && dir != 2 && kidx == nk - 1) ? 1 : 0;
                 uint32_t nbit = 1u << nmx;
-                const uint32_t tv = S.visited[nrot][nmy], tb = vrow[nmy + 1 < MAP_H ? nmy + 1 : nmy];
+                const uint32_t tv = S.visited[nrot][nmy];
                 bool tvis = found & ((tv & nbit) != 0);
-                bool tstuck = (nmy + 1 >= MAP_H) | ((tb & nbit) == 0);
                 bool push = found && !tvis;
                 uint64_t pm = __ballot(push);
                 if (pm) {
@@ -311,7 +314,11 @@ static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int typ
                     tail += __popcll(pm);
                     if (tail > QCAP) { *overflow = 1; tail = QCAP; }
                 }
-                emit_flagged(S, found && tvis && tstuck, nrot, nmy, nbit, nul, lane, isT);   // :474-480
+                if (isT) {                                                                  // :474-480
+                    const uint32_t tb = vrow[nmy + 1 < MAP_H ? nmy + 1 : nmy];
+                    const bool tstuck = (nmy + 1 >= MAP_H) | ((tb & nbit) == 0);
+                    emit_flagged(S, found && tvis && tstuck, nrot, nmy, nbit, nul, lane, true);
+                }
             }
             wave_sync();
             PROF_T(q4); PROF_ADD(4, q3, q4); PROF_ADD(10, 0ull, (unsigned long long)((n_tasks + 63) / 64));
@@ -328,8 +335,9 @@ static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int typ
                 int row = lane;
                 if (row < TRL_POLICY_ROWS) {
                     auto src = [&](int o, int my) -> uint32_t {
-                        uint32_t p = S.present[o][my], f = S.flagp[o][my], u = S.ulp[o][my];
-                        if (!isT) return p | f;
+                        uint32_t p = S.present[o][my];
+                        if (!isT) return p;                                  // flagged placements are a subset (emit_flagged)
+                        uint32_t f = S.flagp[o][my], u = S.ulp[o][my];
                         return ts == 0 ? (p & ~f) : (ts == 1 ? (f & ~u) : (f & u));
                     };
                     m = src(ri, row + 2);
