@@ -150,6 +150,7 @@ int trl_engine_create(const trl_config *cfg, trl_engine **out) {
     if (!h) return fail(TRL_E_INVALID, "trl_engine_create: %s", "out of host memory");
     memset(h, 0, sizeof *h);
     h->cfg = *cfg;
+    h->n_cu = prop.multiProcessorCount;
     auto alloc = [&]() -> int {
         if (cfg->stream) { h->stream = (hipStream_t)cfg->stream; h->own_stream = false; }
         else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
@@ -319,9 +320,7 @@ int trl_env_rollout_random(trl_engine *h, int n_plies, int max_plies, uint64_t *
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipMemsetAsync(h->d_steps, 0, 2 * sizeof(unsigned long long), h->stream));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, h->cfg.device));
-    const int pacing = h->cfg.n_games <= 16 * prop.multiProcessorCount;     // 16 workgroups of this kernel fit a CU
+    const int pacing = h->cfg.n_games <= 16 * h->n_cu;                      // 16 workgroups of this kernel fit a CU
     hipLaunchKernelGGL(k_rollout, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->d_states, h->cfg.seed,
                        n_plies, max_plies, h->d_steps, pacing);
     HIPCHK(hipGetLastError());

@@ -87,6 +87,7 @@ struct trl_engine {
     bool have_reset;
     float last_ms;
     trl_mcts *mcts;
+    int n_cu = 0;                          // compute units of the device (rollout pacing: are all slots resident?)
     hipGraph_t graph = nullptr;            // captured search tick (trl_graph_begin / _end / _launch)
     hipGraphExec_t graph_exec = nullptr;
 };
