@@ -84,6 +84,16 @@ def test_make_training_set_is_wellformed_and_deterministic(tmp_path, monkeypatch
     # the file comes from the text writer (records built as JSON text): same bytes as json.dumps of the list path
     same = trl.make_training_set(cfg, net, 2, save_game=False, save_stats=False, seed=3)
     assert open(os.path.join(cfg.data_dir, "0.txt")).read() == json.dumps(same)
+    # write_json=False: the set exists in packed form only (same content as set 0's packed file), and the learner reads it
+    from tetris_rl_amd import learner
+    trl.make_training_set(cfg, net, 2, save_game=True, save_stats=True, seed=3, write_json=False)
+    assert not os.path.exists(os.path.join(cfg.data_dir, "1.txt")) and trl.highest_data_number(cfg) == 1
+    p0, p1 = (np.load(os.path.join(learner.packed_dir(cfg), "%d.npz" % k)) for k in (0, 1))
+    assert all(np.array_equal(p0[k], p1[k]) for k in p0.files)
+    os.remove(os.path.join(cfg.data_dir, "0.txt"))                 # both sets now packed-only
+    cfg2 = cfg.copy(); cfg2.batch_size = 16; cfg2.epochs = 1
+    entry = learner.load_data_and_train_model(cfg2, trl.AlphaSame(trl.AlphaSameConfig(blocks=2, filters=8)).cuda())
+    assert entry["loss"] > 0
 
 
 def test_graph_and_eager_ticks_agree():

@@ -143,9 +143,11 @@ def train_network_pytorch(config, model, set, data_number=None, device=None):
 def get_data_filenames(config):
     """ai.py:1943-1973: the newest `sets_to_train_with` set files"""
     path, newest = config.data_dir, selfplay.highest_data_number(config)
-    if not os.path.isdir(path):
-        return []
-    names = [n for n in os.listdir(path) if n.split(".")[0].isdigit() and int(n.split(".")[0]) > newest - config.sets_to_train_with]
+    listed = os.listdir(path) if os.path.isdir(path) else []
+    have = {n.split(".")[0] for n in listed}
+    if os.path.isdir(packed_dir(config)):                        # sets written with write_json=False exist only there
+        listed += ["%s.txt" % n.split(".")[0] for n in sorted(os.listdir(packed_dir(config))) if n.split(".")[0] not in have]
+    names = [n for n in listed if n.split(".")[0].isdigit() and int(n.split(".")[0]) > newest - config.sets_to_train_with]
     if config.shuffle:
         random.shuffle(names)
     return names

@@ -226,9 +226,10 @@ class GameCollector:
     """Groups the device's record stream into finished games and builds the reference's per-game
     `data` lists (ai.py:1613-1695)."""
 
-    def __init__(self, config, as_text=False):
+    def __init__(self, config, as_text=False, packed_only=False):
         self.config = config
         self.as_text = as_text    # build each record as JSON text (records.record_texts_for_move) instead of lists
+        self.packed_only = packed_only   # keep only the packed saved moves (no reference-format records at all)
         self.open = {}            # (slot, episode) -> list of move records
         self.finished = []        # dicts: key, data | texts, stats, plies, winner
 
@@ -244,8 +245,9 @@ class GameCollector:
                 for m in moves:
                     if m["saved"]:
                         n = int(m["n_children"])
-                        game_data[int(m["state"][312])] += per_move(m["state"], m["moves"][:n], m["visits"][:n],
-                                                                    augment=self.config.augment_data)
+                        if not self.packed_only:
+                            game_data[int(m["state"][312])] += per_move(m["state"], m["moves"][:n], m["visits"][:n],
+                                                                        augment=self.config.augment_data)
                         saved[int(m["state"][312])].append((m["state"].copy(), m["moves"][:n].copy(), m["visits"][:n].copy()))
                 c = self.config
                 finish = records.finish_game_texts if self.as_text else records.finish_game
@@ -276,7 +278,9 @@ def highest_model_number(config):
 
 
 def highest_data_number(config):
-    return _highest_number(config.data_dir)
+    """newest set number: {data_dir}/{n}.txt as in the reference, or {data_dir}_packed/{n}.npz of a set written with
+    write_json=False"""
+    return max(_highest_number(config.data_dir), _highest_number(config.data_dir.rstrip("/") + "_packed"))
 
 
 def instantiate_network(config, nn_generator=None, show_summary=False, save_network=True):
@@ -318,12 +322,12 @@ def _play_raw(config, network, num_games, seed, device=0, max_slots=1024, stream
     return recs[np.lexsort((recs["kind"], recs["ply"], recs["slot"], recs["episode"]))]
 
 
-def _play_collect(config, network, num_games, seed, device=0, max_slots=1024, streams=None, as_text=False):
+def _play_collect(config, network, num_games, seed, device=0, max_slots=1024, streams=None, as_text=False, packed_only=False):
     """_play_raw + games_from_records in one pass, with the host's record conversion overlapped with the device: the
     next 64 ticks are enqueued before the records of the previous 64 are turned into training records."""
     slots = min(int(num_games), int(max_slots))
     sp = SelfPlay(config, network, slots, seed=seed, device=device, streams=streams, auto_reset=num_games > slots)
-    col = GameCollector(config, as_text=as_text)
+    col = GameCollector(config, as_text=as_text, packed_only=packed_only)
     ended = []
     sp.tick(64)
     while True:
@@ -353,7 +357,8 @@ def games_from_records(config, recs, as_text=False):
     return col.finished
 
 
-def _run_games(config, network, num_games, seed, device=0, max_slots=1024, streams=None, dist=None, as_text=False):
+def _run_games(config, network, num_games, seed, device=0, max_slots=1024, streams=None, dist=None, as_text=False,
+               packed_only=False):
     """Single process: all num_games here.  With an initialised torch.distributed group: rank r plays
     games [r * G/W, (r+1) * G/W) on its own GPU (disjoint RNG streams, no collective during play) and the
     packed records are gathered to rank 0, which returns all games; other ranks return []."""
@@ -377,7 +382,7 @@ def _run_games(config, network, num_games, seed, device=0, max_slots=1024, strea
         allrecs = np.concatenate([np.frombuffer(p.tobytes(), dtype=_eng.RECORD_DTYPE) for p in parts])
         return games_from_records(config, allrecs, as_text)[:num_games], None
     return _play_collect(config, network, num_games, seed, device=device, max_slots=max_slots, streams=streams,
-                         as_text=as_text)[:num_games], None
+                         as_text=as_text, packed_only=packed_only)[:num_games], None
 
 
 def play_game(config, interference_network, game_number=None, screen=None, seed=0):
@@ -392,16 +397,19 @@ def play_game(config, interference_network, game_number=None, screen=None, seed=
 
 
 def make_training_set(config, interference_network, num_games, save_game=False, save_stats=True, screen=None, seed=0,
-                      max_slots=1024, device=0, dist=None):
+                      max_slots=1024, device=0, dist=None, write_json=True):
     """ai.py:1809-1845: plays num_games games, optionally writes {data_dir}/{n}.txt and the averaged
     stats line; returns the records only when save_stats is False (as the reference does).
     `dist`: an initialised torch.distributed module -> games are sharded over the ranks (one GPU each),
-    records gathered to rank 0 over RCCL; files are written by rank 0 only."""
+    records gathered to rank 0 over RCCL; files are written by rank 0 only.
+    write_json=False (with save_game and save_stats): only the packed set is written -- the reference's JSON layout is
+    ~60 KB of text per record and forming it is what bounds the host; this build's learner reads the packed set."""
     # the records are only written, not returned (the reference's normal call): build them as JSON text directly --
     # the same bytes as json.dumps of the lists at a tenth of the host time (records.record_texts_for_move)
     as_text = bool(save_game and save_stats)
+    packed_only = as_text and not write_json and not (dist is not None and dist.is_initialized() and dist.get_world_size() > 1)
     games, _ = _run_games(config, interference_network, num_games, seed, max_slots=max_slots, device=device, dist=dist,
-                          as_text=as_text)
+                          as_text=as_text, packed_only=packed_only)
     if dist is not None and dist.is_initialized() and dist.get_rank() != 0:
         return None
     series_data, series_stats = [], []
@@ -411,7 +419,9 @@ def make_training_set(config, interference_network, num_games, save_game=False, 
     if save_game:
         os.makedirs(config.data_dir, exist_ok=True)
         next_set = highest_data_number(config) + 1
-        if as_text:
+        if packed_only:
+            pass
+        elif as_text:
             with open("%s/%d.txt" % (config.data_dir, next_set), "wb") as f:
                 f.write(b"[")
                 for i, rec in enumerate(series_data):
@@ -438,7 +448,7 @@ def make_training_set(config, interference_network, num_games, save_game=False, 
     return series_data
 
 
-def self_play_loop(config, skip_first_set=False, max_sets=None, train_fn=None, gate_fn=None, seed=0):
+def self_play_loop(config, skip_first_set=False, max_sets=None, train_fn=None, gate_fn=None, seed=0, write_json=True):
     """ai.py:2117-2198: generate a training set with the best model, train a challenger on the recent
     sets, play the gating match, promote the challenger if it meets the threshold -- forever, or
     `max_sets` times.  `train_fn(config, model)` / `gate_fn(challenger, config, best, config, threshold,
@@ -460,7 +470,7 @@ def self_play_loop(config, skip_first_set=False, max_sets=None, train_fn=None, g
         if not skip_first_set:
             for i in range(config.training_loops):
                 make_training_set(training_config, challenger, config.training_games, save_game=True, save_stats=True,
-                                  seed=seed + 1000 * it + i)
+                                  seed=seed + 1000 * it + i, write_json=write_json)
         else:
             skip_first_set = False
         dev = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
