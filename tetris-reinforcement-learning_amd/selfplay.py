@@ -329,7 +329,13 @@ def _play_collect(config, network, num_games, seed, device=0, max_slots=1024, st
     sp = SelfPlay(config, network, slots, seed=seed, device=device, streams=streams, auto_reset=num_games > slots)
     col = GameCollector(config, as_text=as_text, packed_only=packed_only)
     ended = []
-    sp.tick(64)
+    # ticks between two drains: each drain is a stream sync + copies, ~2 ms against 0.4 ms per tick at 1024 slots; the
+    # device record buffer (default 16 384) must hold what finishes in between: <= slots * chunk / shortest search + games
+    shortest = config.MAX_ITER
+    if config.training and config.use_playout_cap_randomization:
+        shortest = max(1, int(config.MAX_ITER / (config.playout_cap_chance * (config.playout_cap_mult - 1) + 1)))
+    chunk = max(16, min(256, (16384 * shortest) // (2 * slots)))
+    sp.tick(chunk)
     while True:
         r = sp.drain()
         ended += [(int(e), int(sl)) for e, sl in zip(r["episode"][r["kind"] == _eng.REC_GAME_END], r["slot"][r["kind"] == _eng.REC_GAME_END])]
@@ -338,7 +344,7 @@ def _play_collect(config, network, num_games, seed, device=0, max_slots=1024, st
             raise _eng.EngineError("device record buffer or tree capacity overflowed: %r" % (st,))
         done = len(ended) >= num_games
         if not done:
-            sp.tick(64)                                   # the device goes on while the host converts
+            sp.tick(chunk)                                # the device goes on while the host converts
         col.add(r[np.lexsort((r["kind"], r["ply"], r["slot"], r["episode"]))])
         if done:
             break
