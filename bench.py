@@ -35,6 +35,7 @@ SEED = 20260630
 GAMES_PER_GPU = 4096
 BYTES_PER_STEP = 320          # algorithmic bytes of one env-step
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PREROLL_PLIES = 300           # input set-up of C2: ~6 game lengths of random play -> stationary mix of game phases
 
 
 def cpu_baseline(seconds_target=15.0):
@@ -258,11 +259,11 @@ def cpu_baseline_mcts(seconds_target=12.0):
                       % (moves, sims, dt)}
 
 
-def load_pmc_traffic():
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), if present."""
-    path = os.path.join(ROOT, "profiles", "r01_env_rollout_pmc.json")
+def load_pmc(name="r02_env_rollout_pmc.json"):
+    """per-ply figures of k_rollout from the committed rocprofv3 --pmc passes (profiles/): HBM-side bytes per ply and
+    game, vector-ALU instructions per wave and ply -- measured at the launch lengths listed in the file"""
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             return json.load(f)
     except Exception:
         return None
@@ -277,6 +278,54 @@ def cpu_shard(c, per):
     print(ob.rollout_random(1000))
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` started as ONE process: this parent makes no GPU call; it starts N fresh rank processes
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would set them), relays rank 0's JSON line and
+    exits non-zero if any rank does."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    import tempfile
+    fd, line_path = tempfile.mkstemp(prefix="trl_bench_", suffix=".json")
+    os.close(fd)
+    procs, rc = [], 0
+    for r in range(n):
+        # rank 0 writes the JSON line to TRL_BENCH_JSON; the ranks' stdout (gloo / RCCL banners) goes to stderr, so
+        # this process prints the ONE line and nothing else
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TRL_BENCH_JSON=line_path)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=sys.stderr))
+    try:
+        pending = list(procs)
+        while pending and not rc:
+            for p in list(pending):
+                code = p.poll()
+                if code is not None:
+                    pending.remove(p)
+                    rc = rc or code
+            time.sleep(0.05)
+    finally:
+        for p in procs:                                     # a failed rank leaves the others inside a collective:
+            if p.poll() is None:                            # end exactly the processes started here
+                p.terminate()
+                try:
+                    p.wait(timeout=30)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+    with open(line_path) as f:
+        line = f.read()
+    os.unlink(line_path)
+    if rc or not line.strip():
+        sys.stderr.write("bench.py: a rank exited with code %d\n" % rc)
+        raise SystemExit(rc if 0 < rc < 256 else 1)
+    sys.stdout.write(line)
+    sys.stdout.flush()
+
+
 def main():
     if len(sys.argv) == 4 and sys.argv[1] == "--cpu-shard":
         return cpu_shard(int(sys.argv[2]), int(sys.argv[3]))
@@ -285,6 +334,10 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--games", type=int, default=GAMES_PER_GPU, help="games per GPU (C2: 4096)")
+    ap.add_argument("--preroll", type=int, default=PREROLL_PLIES,
+                    help="plies played while the synthetic input is set up, before the warm-up steps: all games start at ply 0 "
+                         "together and random play ends a game after ~50 plies, so the stationary mix of game phases (what "
+                         "C2 means by random-queue boards) is reached only after a few game lengths")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-mcts", action="store_true", help="skip the C3 (MCTS moves/s) measurement")
     ap.add_argument("--mcts-games", type=int, default=1024, help="concurrent self-play games per GPU (C3: 1024)")
@@ -295,17 +348,26 @@ def main():
     ap.add_argument("--c5-warmup", type=int, default=50)
     args = ap.parse_args()
 
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1:
+        return launch_ranks(args.gpus, sys.argv[1:])        # not under torch.distributed.run: start the ranks here
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    # CPU baseline legs first, before this process makes its first GPU call (they start one worker process per core)
+    cpu_c2 = cpu_c3 = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu_c2 = cpu_baseline()
+        if not args.no_mcts:
+            cpu_c3 = cpu_baseline_mcts()
+
     import numpy as np
     import torch
     import tetris_rl_amd as trl
     from tetris_rl_amd import parallel
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
     dist = None
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
@@ -318,6 +380,7 @@ def main():
     local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank) if backend == "nccl" else None
+    dist_info = {"backend": None, "world_size": 1}
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -325,10 +388,13 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}     # what the process group saw
 
     n = args.games
     eng = trl.Engine(n, ruleset="s2", seed=SEED, device=local_rank)
     eng.reset(parallel.game_streams(rank, n))
+    if args.preroll > 0:
+        eng.rollout_random(args.preroll)                     # input set-up: the games reach their stationary phase mix
 
     def barrier():
         if dist is not None:
@@ -359,10 +425,19 @@ def main():
         value = steps_total / elapsed
         per_launch_bytes = BYTES_PER_STEP * (steps_total / world)        # one launch per rank
         achieved = per_launch_bytes / (kernel_ms * 1e-3) / 1e9
-        pmc = load_pmc_traffic()
-        traffic = None
-        if pmc and pmc.get("games") == n and pmc.get("plies") == args.steps:
-            traffic = pmc.get("hbm_bytes_per_launch")
+        pmc = load_pmc()
+        traffic = valu = None
+        if pmc and pmc.get("games") == n:
+            # HBM-side bytes of one launch: the committed per-ply counter figures scaled to this launch's length
+            traffic = int(pmc["hbm_bytes_fixed_per_launch"] + pmc["hbm_bytes_per_ply"] * args.steps)
+            # the bound that binds: vector-instruction issue.  2 waves per game, every wave64 vector instruction holds
+            # its SIMD for VALU_ISSUE_CYCLES cycles (measured, scripts/valu_peak.hip)
+            inst = pmc["valu_inst_per_wave_ply"] * 2 * n * args.steps
+            rate = inst / (kernel_ms * 1e-3)
+            peak = pmc["simds"] * pmc["clock_ghz"] * 1e9 / pmc["valu_issue_cycles"]
+            valu = {"bound": "valu_issue", "achieved": round(rate / 1e9, 2), "peak": round(peak / 1e9, 2),
+                    "unit": "G wave-instructions/s", "frac": round(rate / peak, 4),
+                    "valu_inst_per_wave_ply": pmc["valu_inst_per_wave_ply"], "source": pmc.get("source")}
         out = {
             "metric": "env-steps/sec (HIP env-step kernel, random policy, no MCTS/net)",
             "value": round(value, 1),
@@ -378,23 +453,30 @@ def main():
             "data": "synthetic",
             "config": {"workload": "C2: %d concurrent two-player games per GPU (ruleset s2), uniform-random legal "
                                    "policy, auto-reset on terminal; 1 step = 1 ply of every game" % n,
-                       "games_per_gpu": n, "seed": SEED, "plies_timed": args.steps,
+                       "games_per_gpu": n, "seed": SEED, "plies_timed": args.steps, "preroll_plies": args.preroll,
                        "env_steps_timed": steps_total, "parallelism": "games sharded by rank, no collective"},
+            "dist": dist_info,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic,
                          "kernel": "k_rollout", "kernel_ms": round(kernel_ms, 4),
                          "algorithmic_bytes_per_step": BYTES_PER_STEP,
-                         "note": "integer/latency-bound search; HBM is nominal (SURVEY 8d)"},
+                         "note": "integer/latency-bound search; HBM is nominal (SURVEY 8d); the binding bound is roofline_valu"},
         }
+        if valu is not None:
+            out["roofline_valu"] = valu
         if mcts is not None:
             out["mcts"] = mcts
         if c5 is not None:
             out["mcts_c5"] = c5
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-            if mcts is not None:
-                out["mcts"]["cpu_baseline"] = cpu_baseline_mcts()
-        print(json.dumps(out), flush=True)
+        if cpu_c2 is not None:
+            out["cpu_baseline"] = cpu_c2
+            if mcts is not None and cpu_c3 is not None:
+                out["mcts"]["cpu_baseline"] = cpu_c3
+        if os.environ.get("TRL_BENCH_JSON"):                  # started by launch_ranks: the parent prints the line
+            with open(os.environ["TRL_BENCH_JSON"], "w") as f:
+                f.write(json.dumps(out) + "\n")
+        else:
+            print(json.dumps(out), flush=True)
 
     if dist is not None:
         dist.barrier()

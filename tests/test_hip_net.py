@@ -9,7 +9,7 @@ import torch
 
 import tetris_rl_amd as trl
 from tetris_rl_amd import records
-from test_net_parity import load_net, packed_features, TOL
+from test_net_parity import load_net, packed_features, load_formula_net, DEEP, TOL
 
 pytestmark = pytest.mark.gpu
 
@@ -188,6 +188,24 @@ def test_wide_fused_tower(golden_dir, tag, blocks, filters):
     assert torch.equal(c[need.bool()], a[need.bool()]) and not c[~need.bool()].any()
 
 
+@pytest.mark.parametrize("tag", sorted(DEEP))
+def test_deep_and_tanh_nets_on_device(golden_dir, tag):
+    """C5's net at its full depth on k_trunk_wide<64> (40 convolutions, K = 576, fp32 MFMA accumulation) and the tanh
+    value head on k_trunk16: the reference's values and all 11 583 logits within 1e-5"""
+    blocks, filters, salt, use_tanh = DEEP[tag]
+    d = np.load(os.path.join(golden_dir, "net_deep.npz"))
+    net = load_formula_net(blocks, filters, salt, use_tanh, device="cuda")
+    assert net._folded["packed_tower"] is not None and net.use_hip_trunk
+    grids, vec = packed_features(np.load(os.path.join(golden_dir, "net.npz"))["states"])
+    v, logits = net.heads(torch.from_numpy(grids).cuda(), torch.from_numpy(vec).cuda())
+    v = (torch.tanh(v) if use_tanh else torch.sigmoid(v)).cpu().numpy()
+    assert np.abs(v - d["%s/values" % tag]).max() < TOL
+    assert np.abs(logits.cpu().numpy() - d["%s/logits" % tag]).max() < TOL
+    # inside a batch of 256 (other tiles, other workgroups) the same positions give the same numbers
+    vb, lb = net.heads(torch.from_numpy(np.tile(grids, (1, 32, 1))).cuda(), torch.from_numpy(np.tile(vec, (32, 1))).cuda())
+    assert np.abs(lb[-8:].cpu().numpy() - d["%s/logits" % tag]).max() < TOL
+
+
 @pytest.mark.parametrize("tag", ["base32", "aux32"])
 def test_baseresnet_fused_tower(golden_dir, tag):
     """trl_resnet_trunk (k_trunk_wide<32, POST>): the reference's BaseResNet / AuxBaseResNet outputs within 1e-5
@@ -351,3 +369,60 @@ def test_device_heads_match_torch_heads():
         assert np.allclose(p0[g, :n], p1[g, :n], rtol=2e-5, atol=1e-9)
         assert np.allclose(q0[g, :n], q1[g, :n], rtol=0, atol=2e-6)
     assert int((r0["chosen"] == r1["chosen"]).sum()) >= 60
+
+
+def test_production_tick_matches_reference_priors(golden_dir):
+    """The default SelfPlay tick (policy_head="legal", tower cache, heads inside k_expand<2>) next to numbers derived
+    from the REFERENCE's outputs on the net.npz positions (not from this build's PyTorch heads): after one tick with
+    those positions as roots, every root child's prior equals ai.py:411-443 applied to the reference's logits
+    (softmax -> `<= 0 -> 1e-25` -> root softmax exp((ln p - ln p_max) / 1.1) -> normalise, in Python floats), and the
+    children's first-play-urgency value equals 1 - value_ref (ai.py:447-453).  Then a second tick: the child the
+    reference's PUCT rule picks from those priors is the one the device visited."""
+    import math
+    import oracle_py as op
+    d = np.load(os.path.join(golden_dir, "net.npz"))
+    states = d["states"]
+    n = len(states)
+    net = load_net(d, "b10f16", 10, 16, device="cuda")
+    cfg = trl.Config(visual=False, model="pytorch", model_config=trl.AlphaSameConfig(blocks=10, filters=16), MAX_ITER=160,
+                     training=False)
+    sp = trl.SelfPlay(cfg, net, n, seed=3, auto_reset=False)
+    assert sp.policy_head == "legal" and sp.tower_cache and sp.heads is not None and sp.native_graph   # the production path
+    sp.engine.set_state(states)
+    sp.tick(1)
+    sp.synchronize()
+    counts, moves, visits, q, p = sp.engine.mcts_root_children()
+    logits = d["b10f16/logits"].astype(np.float32)
+    want_children = []
+    for g in range(n):
+        legal = op.OracleGame(state=states[g]).legal_moves()
+        assert counts[g] == len(legal) > 0 and np.array_equal(moves[g, :counts[g]], legal)
+        probs = torch.softmax(torch.from_numpy(logits[g]), dim=0).numpy()              # evaluate_pytorch, ai.py:1315-1318
+        probs[probs <= 0] = 1e-25
+        idx = [((int(m) >> 10) & 31) * 429 + ((int(m) >> 4) & 63) * 11 + (int(m) & 15) for m in legal]
+        pol = [probs[i] for i in idx]                                                   # np.float32 scalars, as in the reference
+        log_max, inv_temp = math.log(max(pol)), 1.0 / cfg.RootSoftmaxTemp
+        pol = [math.exp((math.log(x) - log_max) * inv_temp) for x in pol]
+        s = sum(pol)
+        want = np.array([x / s for x in pol])
+        want_children.append(want)
+        got = p[g, :counts[g]]
+        assert np.abs(got - want).max() < 1e-6 and np.abs(got / want - 1).max() < 2e-5, (g, np.abs(got / want - 1).max())
+        v_ref = float(d["b10f16/values"][g])
+        assert np.abs(q[g, :counts[g]] - (1.0 - v_ref)).max() < TOL                   # max(value_min, 1 - v), ai.py:447-453
+        assert (visits[g, :counts[g]] == 0).all()
+    # second simulation: selection by Q + c * P * sqrt(N_parent) / d over unvisited children, last maximum wins
+    # (ai.py:346-393); skipped where the reference's own top two scores are closer than the prior tolerance
+    sp.tick(1)
+    sp.synchronize()
+    _, _, visits2, _, _ = sp.engine.mcts_root_children()
+    checked = 0
+    for g in range(n):
+        score = (1.0 - float(d["b10f16/values"][g])) + cfg.CPUCT * want_children[g] * math.sqrt(1.0) / cfg.DPUCT
+        order = np.sort(score)
+        if order[-1] - order[-2] < 1e-6:
+            continue
+        best = int(np.nonzero(score == score.max())[0][-1])
+        assert visits2[g, :counts[g]].sum() == 1 and visits2[g, best] == 1
+        checked += 1
+    assert checked >= 6

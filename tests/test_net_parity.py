@@ -77,6 +77,34 @@ def test_wide_towers_match_reference(golden_dir, tag, blocks, filters):
     assert np.abs(logits.numpy() - d["%s/logits" % tag]).max() < TOL
 
 
+def load_formula_net(blocks, filters, salt, use_tanh=False, device="cpu"):
+    """AlphaSame with every weight from net_fixture.formula_state_dict (the recipe of oracle/gen_golden_net_deep.py)"""
+    net = nets.AlphaSame(nets.AlphaSameConfig(blocks=blocks, filters=filters), use_tanh=use_tanh)
+    sd = net_fixture.formula_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, salt=salt)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    return net.to(device).prepare()
+
+
+DEEP = {"b20f64": (20, 64, 2064, False), "b10f16tanh": (10, 16, 1016, True)}
+
+
+@pytest.mark.parametrize("tag", sorted(DEEP))
+def test_deep_and_tanh_nets_match_reference(golden_dir, tag):
+    """BASELINE config C5's net at full depth (20 blocks x 64 filters = 40 convolutions of K = 576) and the tanh value
+    head (architectures.py:116), against the reference's outputs on the net.npz positions"""
+    blocks, filters, salt, use_tanh = DEEP[tag]
+    d = np.load(os.path.join(golden_dir, "net_deep.npz"))
+    net = load_formula_net(blocks, filters, salt, use_tanh)
+    assert list(net.state_dict().keys()) == [str(k) for k in d["%s/keys" % tag]]
+    grids, vec = packed_features(np.load(os.path.join(golden_dir, "net.npz"))["states"])
+    v, logits = net.heads(torch.from_numpy(grids), torch.from_numpy(vec))
+    v = (torch.tanh(v) if use_tanh else torch.sigmoid(v)).numpy()
+    assert np.abs(v - d["%s/values" % tag]).max() < TOL
+    assert np.abs(logits.numpy() - d["%s/logits" % tag]).max() < TOL
+    if use_tanh:
+        assert (d["%s/values" % tag] < 0).any()                 # the fixture does exercise the negative half of the range
+
+
 def test_reference_checkpoint_roundtrip(tmp_path, golden_dir):
     d = np.load(os.path.join(golden_dir, "net.npz"))
     net = load_net(d, "b2f8", 2, 8)

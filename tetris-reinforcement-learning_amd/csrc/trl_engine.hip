@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <new>
 #include "trl_internal.h"
 
@@ -64,30 +65,48 @@ __global__ __launch_bounds__(BLOCK) void k_step(trl_game_state *states, const ui
     store_state(sh, states + game, tid);
 }
 
+#ifdef TRL_SLOT_TIMES
+__device__ unsigned long long g_slot_t[2 * 16384];     // per slot: wall clock at the start / end of its part of the last rollout launch
+#endif
+
 // C2 workload: n_plies x { legal -> uniform pick -> make_move(add_bag) -> re-setup when finished }
-// Pacing: every game plays its plies in sequence, so the launch ends with the slot whose games were the most expensive.
-// Slots publish their progress (one atomic per 16 plies) and a slot that has fallen behind the mean raises its waves'
-// issue priority over the co-resident slots that are ahead -- the stragglers catch up while the CU is still full
-// instead of finishing alone at single-wave speed.  Scheduling only: the games are the same.  (Only when all slots
-// are resident at once: with more slots than residency the hardware refills the CUs and late starters are not behind.)
+// Pacing.  Every game plays its plies in sequence and all slots are resident at once (16 workgroups per CU).  The issue
+// arbiter of a SIMD serves its OLDEST ready wave first, so the workgroups dispatched first run up to twice as fast as
+// the last ones: unpaced, the first slot of a 1000-ply launch is done after 21.7 ms, the median after 30 ms, the last
+// after 42.9 ms, the chip emptying out all the while (profiles/r02/r02c_rollout_tail.txt).  Slots therefore publish
+// their progress and set their waves' issue priority (s_setprio) by how far behind the others they are.  Scheduling
+// only -- the games are the same bit for bit.
+//   After every ply a slot stores its ply count in prog[] and reads the 64 counts of its comparison set (one per lane,
+//   from L2, no shared counter); its rank in the set (members that are further behind) picks the priority: the r3
+//   least advanced get 3, the next up to r2 get 2, up to r1 get 1, the rest 0 (`rankt` = r3 | r2 << 8 | r1 << 16;
+//   0 = pacing off).  The set of slot g is {g % S + j * S, j = 0..63}, S = ceil(slots / 64): 64 slots spread evenly over
+//   the dispatch order -- neighbours in the grid have the same age, and comparing a slot with them shows nothing.
+//   Round 1 used one global counter (an atomic per slot and 16 plies, ~30 ns each, serialised): as good on launches of
+//   1000 plies (34.0 us per ply against 35.1 here) but too slow to react on short ones (50 us per ply at 20 plies per
+//   launch against 40.7 here; profiles/r02/r02a_rollout_regime.txt, r02f_rollout_tail.txt).  What remains at 20 plies
+//   is the critical path of the most expensive games: even with the SIMD to itself a wave needs ~25 us for a ply.
 __global__ __launch_bounds__(BLOCK, 8) void k_rollout(trl_game_state *states, uint64_t seed, int n_plies, int max_plies,
-                                                   unsigned long long *steps_total, int pacing) {
+                                                   unsigned long long *steps_total, unsigned int *prog, int rankt) {
     __shared__ BlockShared sh;
     const int tid = threadIdx.x, game = blockIdx.x;
-    unsigned long long *progress = (steps_total && pacing) ? steps_total + 1 : nullptr;
+#ifdef TRL_SLOT_TIMES
+    const unsigned long long t_begin = wall_clock64();
+#endif
     load_state(sh, states + game, tid);
-    if (tid == 0) sh.done = 0;
     __syncthreads();
     int steps = 0;
     for (int k = 0; k < n_plies; k++) {
-        if (progress && (k & 15) == 0) {
-            if (tid == 0) {
-                if (k) atomicAdd(progress, 16ull);
-                const unsigned long long tot = __hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                sh.done = ((unsigned long long)(k + 6) * gridDim.x < tot) ? 1 : 0;     // more than 6 plies behind the mean
-            }
-            __syncthreads();
-            if (sh.done) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+        if (rankt && k) {
+            // both waves look for themselves (no barrier); the counts of a set are contiguous in prog[] (256 bytes)
+            const int lane = tid & 63, S = ((int)gridDim.x + 63) >> 6, set = game % S;
+            const bool member = set + lane * S < (int)gridDim.x;
+            const unsigned int theirs = member ? __hip_atomic_load(prog + set * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                               : (unsigned int)k;
+            const int rank = (int)__popcll(__ballot(member && theirs < (unsigned int)k));   // members that are behind this slot
+            if (rank < (rankt & 255)) __builtin_amdgcn_s_setprio(3);
+            else if (rank < ((rankt >> 8) & 255)) __builtin_amdgcn_s_setprio(2);
+            else if (rank < ((rankt >> 16) & 255)) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
         }
         int total = block_movegen(sh, tid);
         if (tid < 64) {
@@ -106,11 +125,18 @@ __global__ __launch_bounds__(BLOCK, 8) void k_rollout(trl_game_state *states, ui
                 game_setup(g, ruleset, seed, stream);
                 g.episode = episode; g.flags = flags;
             }
+            if (rankt && tid == 0) {
+                const int S = ((int)gridDim.x + 63) >> 6;
+                __hip_atomic_store(prog + (game % S) * 64 + game / S, (unsigned int)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         __syncthreads();
     }
     store_state(sh, states + game, tid);
     if (tid == 0 && steps_total) atomicAdd(steps_total, (unsigned long long)steps);
+#ifdef TRL_SLOT_TIMES
+    if (tid == 0) { g_slot_t[2 * game] = t_begin; g_slot_t[2 * game + 1] = wall_clock64(); }    // 100 MHz chip-wide clock
+#endif
 }
 
 // exhaustive check of the integer attack formulas against stats.py (tests only)
@@ -159,14 +185,15 @@ int trl_engine_create(const trl_config *cfg, trl_engine **out) {
         HIPCHK(hipMalloc(&h->d_counts, n * sizeof(uint16_t)));
         HIPCHK(hipMalloc(&h->d_moves, n * TRL_MAX_LEGAL * sizeof(uint16_t)));
         HIPCHK(hipMalloc(&h->d_in_moves, n * sizeof(uint16_t)));
-        HIPCHK(hipMalloc(&h->d_steps, 2 * sizeof(unsigned long long)));       // [0] steps, [1] pacing counter
+        HIPCHK(hipMalloc(&h->d_steps, 2 * sizeof(unsigned long long)));       // [0] steps
+        HIPCHK(hipMalloc(&h->d_prog, (n + 63) / 64 * 64 * sizeof(unsigned int)));              // plies played in this launch, per slot (rollout pacing)
         HIPCHK(hipEventCreate(&h->ev0));
         HIPCHK(hipEventCreate(&h->ev1));
         return TRL_OK;
     };
     int rc = alloc();
     if (rc != TRL_OK) {                            // release what was allocated before the failure
-        hipFree(h->d_states); hipFree(h->d_counts); hipFree(h->d_moves); hipFree(h->d_in_moves); hipFree(h->d_steps);
+        hipFree(h->d_states); hipFree(h->d_counts); hipFree(h->d_moves); hipFree(h->d_in_moves); hipFree(h->d_steps); hipFree(h->d_prog);
         if (h->ev0) hipEventDestroy(h->ev0);
         if (h->ev1) hipEventDestroy(h->ev1);
         if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -184,7 +211,7 @@ void trl_engine_destroy(trl_engine *h) {
     trl_mcts_free_internal(h);
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
     if (h->graph) hipGraphDestroy(h->graph);
-    hipFree(h->d_states); hipFree(h->d_counts); hipFree(h->d_moves); hipFree(h->d_in_moves); hipFree(h->d_steps);
+    hipFree(h->d_states); hipFree(h->d_counts); hipFree(h->d_moves); hipFree(h->d_in_moves); hipFree(h->d_steps); hipFree(h->d_prog);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
@@ -319,10 +346,15 @@ int trl_env_rollout_random(trl_engine *h, int n_plies, int max_plies, uint64_t *
     if (!h->have_reset) return fail(TRL_E_STATE, "%s", "trl_env_rollout_random before trl_env_reset / trl_env_set_state");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipMemsetAsync(h->d_steps, 0, 2 * sizeof(unsigned long long), h->stream));
+    int pacing = h->cfg.n_games <= 16 * h->n_cu;                            // 16 workgroups of this kernel fit a CU
+    int r3 = 4, r2 = 16, r1 = 40;                                           // ranks (of 64) that get priority 3 / 2 / 1
+    if (const char *e = getenv("TRL_PACE")) pacing = atoi(e) != 0;          // probe knobs (scripts/rollout_tail_probe.py)
+    if (const char *e = getenv("TRL_PACE_R")) sscanf(e, "%d,%d,%d", &r3, &r2, &r1);
+    const int rankt = pacing ? ((r3 & 255) | ((r2 & 255) << 8) | ((r1 & 255) << 16)) : 0;
+    if (rankt) HIPCHK(hipMemsetAsync(h->d_prog, 0, ((size_t)h->cfg.n_games + 63) / 64 * 64 * sizeof(unsigned int), h->stream));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    const int pacing = h->cfg.n_games <= 16 * h->n_cu;                      // 16 workgroups of this kernel fit a CU
     hipLaunchKernelGGL(k_rollout, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->d_states, h->cfg.seed,
-                       n_plies, max_plies, h->d_steps, pacing);
+                       n_plies, max_plies, h->d_steps, h->d_prog, rankt);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     if (steps_out) {
@@ -343,6 +375,12 @@ int trl_last_kernel_ms(trl_engine *h, float *ms_out) {
     return TRL_OK;
 }
 
+#ifdef TRL_SLOT_TIMES
+int trl_debug_slot_times(unsigned long long *host_out, int n) {
+    HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_slot_t), sizeof(unsigned long long) * 2 * (size_t)n));
+    return TRL_OK;
+}
+#endif
 #ifdef TRL_PROFILE
 int trl_debug_prof(unsigned long long *host_out, int reset) {
     HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(trl::g_prof), sizeof(unsigned long long) * 16));

@@ -83,6 +83,7 @@ struct trl_engine {
     trl_game_state *d_states;
     uint16_t *d_counts, *d_moves, *d_in_moves;
     unsigned long long *d_steps;
+    unsigned int *d_prog;
     hipEvent_t ev0, ev1;
     bool have_reset;
     float last_ms;
