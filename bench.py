@@ -105,12 +105,21 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
         k = min(512, args.mcts_ticks - done)
         sp.tick(k)
         done += k
-        drained.append(sp.drain().copy())              # records leave the device inside the timed region
+        drained.append(sp.drain_dev())                 # records leave the search's buffer inside the timed region, stay in HBM
     sp.synchronize()
-    # C4: the one exchange step of the path -- every rank's packed (state, pi, z) move records to rank 0 over RCCL
-    mine = np.concatenate(drained) if drained else np.zeros(0, dtype=trl.RECORD_DTYPE)
-    parts = parallel.gather_bytes(mine.view(np.uint8).reshape(-1), dist, dev)
-    gathered = sum(p.size for p in parts) if parts is not None else 0
+    # C4: the one exchange step of the path -- every rank's packed (state, pi, z) move records to rank 0: over RCCL
+    # GPU -> GPU (dist.gather, no host bounce on the senders), then one copy to rank 0's host
+    with torch.cuda.stream(sp.stream):
+        mine = torch.cat(drained) if drained else torch.zeros(0, dtype=torch.uint8, device=sp.device)
+    sp.synchronize()
+    if parallel.active(dist):
+        if dev is None:                                # gloo rehearsal: the backend moves host memory
+            mine = mine.cpu()
+        sizes = parallel.all_gather_ints([mine.numel()], dist, dev)[:, 0]
+        parts = parallel.gather_tensor(mine, sizes, dist)
+        gathered = sum(int(p.cpu().numel()) for p in parts) if parts is not None else 0
+    else:
+        gathered = int(mine.cpu().numel())
     barrier()
     elapsed = time.perf_counter() - t0
     st1 = sp.stats()
@@ -143,7 +152,7 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
                                % n, "games_per_gpu": n, "ticks_timed": args.mcts_ticks, "moves_timed": moves_total,
                    "simulations_timed": sims_total,
                    "records_to_rank0_mb": round(gathered / 1e6, 1),
-                   "parallelism": "games sharded by rank; move records gathered to rank 0 (RCCL all_gather) in the timed region"},
+                   "parallelism": "games sharded by rank; move records gathered to rank 0 (dist.gather, GPU to GPU) in the timed region"},
         "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "kernel": "k_trunk16",
                      "kernel_ms": round(trunk_ms, 4), "flop_per_board": TRUNK_FLOP_PER_BOARD, "boards_per_launch": 2 * n},

@@ -158,6 +158,14 @@ int  trl_env_state_dev(trl_engine *h, void **dev_out);
  * counts[g] placements, moves[g*TRL_MAX_LEGAL + i] ascending.  Terminal / no-move games
  * give 0.  Results stay in HBM (trl_env_legal_dev); host pointers may be NULL.               */
 int  trl_env_legal_moves(trl_engine *h, uint16_t *host_counts, uint16_t *host_moves);
+/* get_move_matrix(player, algo) with the reference's algorithm argument (move_generation.py:752-790, 145-151):
+ * TRL_ALGO_BRUTE_FORCE is the reference's DEFAULT argument ('brute-force', move_generation.py:204-243, what its own
+ * tests call, tests.py:13-58), TRL_ALGO_CONVOLUTIONAL the one Config.move_algorithm defaults to and the search uses
+ * (ai.py:84,414).  The two differ only in the T-spin sub-plane of a few placements.  Any other value: TRL_E_INVALID
+ * (the reference raises ValueError for an unknown name; its lossy 'faster-but-loss' / 'harddrop' are not built).    */
+#define TRL_ALGO_CONVOLUTIONAL 0
+#define TRL_ALGO_BRUTE_FORCE   1
+int  trl_env_legal_moves_algo(trl_engine *h, int algo, uint16_t *host_counts, uint16_t *host_moves);
 int  trl_env_legal_dev(trl_engine *h, void **dev_counts, void **dev_moves);
 
 /* Game.make_move(move, add_bag, add_history=False) for every game (game.py:40-98).
@@ -200,6 +208,11 @@ int  trl_last_kernel_ms(trl_engine *h, float *ms_out);
  *   p = 3 playout-cap coin, p = 4 temperature pick: uniform double ((u64 >> 11) + 0.5) * 2^-53;
  *   p = 5 root noise, gamma(alpha) by Marsaglia-Tsang on alpha + 1 with the u^(1/alpha) boost,
  *         counter ((ply * 512 + child) * 64 + attempt) * 4 + k.
+ *   p = 6  number of random starting moves of a game (np.random.exponential(0.04 * DIRICHLET_S), ai.py:1592-1593):
+ *         -scale * log(uniform at c = 0); one more move is played at random while the remainder is > 0
+ *   random starting move (random_start, ai.py:1588-1608): a search of ONE simulation without playout cap, noise or
+ *         forced playouts, then pick_random_move_by_policy (ai.py:999-1014) = random.choices(moves, priors of the
+ *         root children): itertools.accumulate, x = uniform(p = 4, c = ply) * total, bisect over [0, n - 1).
  */
 typedef struct trl_mcts_config {      /* Config fields the search reads (ai.py:63-138) */
     int32_t max_iter;                 /* MAX_ITER */
@@ -214,6 +227,10 @@ typedef struct trl_mcts_config {      /* Config fields the search reads (ai.py:6
     int32_t max_nodes;                /* tree capacity per slot (0 = default 65536) */
     int32_t record_capacity;          /* records held on the device between drains (0 = default) */
     int32_t auto_reset;               /* 1: a finished game is set up again on a fresh stream */
+    int32_t use_tanh;                 /* Config.use_tanh: value range -1..1 (value_min / mid / max, negate_value, ai.py:198-216) */
+    int32_t random_start;             /* Config.use_random_starting_moves: see below */
+    int32_t episodes_base;            /* with auto_reset: slot s plays episodes_base + (s < episodes_extra) games, then idles */
+    int32_t episodes_extra;           /* (0, 0 = no limit).  Episode e of a slot runs on RNG stream + e * 2^24: at most 256 */
     double  cpuct, dpuct;             /* CPUCT, DPUCT */
     double  fpu_value;                /* FpuValue */
     double  root_softmax_temp;        /* RootSoftmaxTemp */
@@ -238,7 +255,7 @@ typedef struct trl_record {
     int8_t   winner;                  /* GAME_END: Game.winner (game.py:217-225), -1 = draw */
     uint16_t chosen;                  /* MOVE: the move played */
     uint8_t  saved;                   /* MOVE: save_move or save_all (ai.py:1613) */
-    uint8_t  pad_;
+    uint8_t  random_move;             /* MOVE: a random starting move (ai.py:1588-1608): never saved, visits are zero */
     trl_game_state state;             /* MOVE: the position searched (game_to_X input, ai.py:1617); GAME_END: final */
     uint16_t moves[TRL_MAX_LEGAL];    /* root children: encoded moves ... */
     uint16_t visits[TRL_MAX_LEGAL];   /* ... and visit counts (search_statistics input, ai.py:1330) */
@@ -305,6 +322,9 @@ int  trl_mcts_expand_alphasame_masked(trl_engine *h, const float *dev_z, const f
                                       const uint8_t *dev_slot_mask, int want, int last);
 /* copy out and clear the pending records (host buffer of `cap` records); returns the count in *n_out */
 int  trl_mcts_drain_records(trl_engine *h, trl_record *host_out, int cap, int *n_out);
+/* the same into a DEVICE buffer of `cap` records (the gather of the records to rank 0 then runs GPU -> GPU over
+ * RCCL / xGMI without touching the sender's host); the copy is queued on the engine's stream, the count is returned */
+int  trl_mcts_drain_records_dev(trl_engine *h, trl_record *dev_out, int cap, int *n_out);
 int  trl_mcts_get_stats(trl_engine *h, trl_mcts_stats *host_out);
 /* leaf positions of the current tick (after trl_mcts_select), n_games canonical states; and per
  * slot {simulation index, simulations of this search, leaf kind 0 expand / 1 eval only / 2 terminal,

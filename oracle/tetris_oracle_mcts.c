@@ -111,7 +111,9 @@ int to_mcts(to_game *game, const to_mcts_config *cfg, to_eval_fn eval, void *ctx
     T.cap_nodes = 1 << 14; T.n_nodes = 0; T.nodes = (mnode *)malloc(sizeof(mnode) * (size_t)T.cap_nodes);
     T.cap_states = 512; T.n_states = 0; T.states = (to_game *)malloc(sizeof(to_game) * (size_t)T.cap_states);
     float *policy = (float *)malloc(sizeof(float) * TRL_POLICY_SIZE);
-    const double value_min = 0.0, value_max = 1.0, value_mid = 0.5;     /* use_tanh=False (ai.py:198-216) */
+    /* Config.value_min / value_mid / value_max / negate_value (ai.py:198-216) */
+    const double value_min = cfg->use_tanh ? -1.0 : 0.0, value_max = 1.0, value_mid = cfg->use_tanh ? 0.0 : 0.5;
+#define NEGATE(v) (cfg->use_tanh ? -(v) : 1.0 - (v))
 
     /* root: game.copy() with previews restricted to 5 (ai.py:304-313) */
     int root = new_node(&T, -1, -1);
@@ -224,7 +226,7 @@ int to_mcts(to_game *game, const to_mcts_config *cfg, to_eval_fn eval, void *ctx
                 T.nodes[node].first_child = first; T.nodes[node].n_children = n;
                 for (int k = 0; k < n; k++) {                               /* FPU init (ai.py:447-453) */
                     mnode *c = &T.nodes[first + k];
-                    if (cfg->fpu_reduction) { double pv = 1.0 - value; c->value_avg = pv > value_min ? pv : value_min; }
+                    if (cfg->fpu_reduction) { double pv = NEGATE(value); c->value_avg = pv > value_min ? pv : value_min; }
                     else c->value_avg = cfg->fpu_value > value_min ? cfg->fpu_value : value_min;
                 }
             }
@@ -250,8 +252,8 @@ int to_mcts(to_game *game, const to_mcts_config *cfg, to_eval_fn eval, void *ctx
             }
         }
         /* BACKUP (ai.py:504-533) */
-        value = 1.0 - value;
-        double pos_value = value, neg_value = 1.0 - value;
+        value = NEGATE(value);
+        double pos_value = value, neg_value = NEGATE(value);
         int final_turn = lg->turn;
         for (int n = node; ; n = T.nodes[n].parent) {
             mnode *nd = &T.nodes[n];
@@ -270,7 +272,7 @@ int to_mcts(to_game *game, const to_mcts_config *cfg, to_eval_fn eval, void *ctx
                     mnode *c = &T.nodes[pn->first_child + k];
                     if (c->visit_count > 0) { explored = any ? explored + (float)c->policy : (float)c->policy; any = 1; }
                 }
-                double fpu = (1.0 - pn->value_avg) - cfg->fpu_value * sqrt((double)explored);
+                double fpu = NEGATE(pn->value_avg) - cfg->fpu_value * sqrt((double)explored);
                 if (!(fpu > value_min)) fpu = value_min;
                 for (int k = 0; k < pn->n_children; k++) {
                     mnode *c = &T.nodes[pn->first_child + k];
@@ -333,6 +335,8 @@ int to_mcts(to_game *game, const to_mcts_config *cfg, to_eval_fn eval, void *ctx
     out->n_root_children = n;
     out->n_nodes = T.n_nodes;
     out->root_visit = rt->visit_count;
+    out->root_p_f32 = n > 0 ? T.nodes[rt->first_child].prior_f32 : 0;
+#undef NEGATE
     for (int k = 0; k < n && k < TRL_MAX_LEGAL; k++) {
         mnode *c = &T.nodes[rt->first_child + k];
         out->root_moves[k] = (uint16_t)c->move; out->root_visits[k] = c->visit_count;
@@ -375,6 +379,12 @@ void to_stub_eval(const to_game *g, float *value, float *policy, void *ctx) {
     to_stub_eval_state(&s, value, policy);
 }
 
+/* the stub for a tanh-range net (Config.use_tanh): value 2 v - 1 in [-1, 1), exact in float32 */
+void to_stub_eval_tanh(const to_game *g, float *value, float *policy, void *ctx) {
+    to_stub_eval(g, value, policy, ctx);
+    *value = 2.0f * *value - 1.0f;
+}
+
 /* a second deterministic evaluator for the gating tests: the stub with a salted hash (ctx = &salt) */
 void to_stub_eval_salted(const to_game *g, float *value, float *policy, void *ctx) {
     trl_game_state s;
@@ -411,7 +421,7 @@ int to_play_battle_stub(to_game *g, const to_mcts_config *cfg, int side, uint64_
 }
 
 int to_mcts_stub(to_game *game, const to_mcts_config *cfg, to_mcts_result *out) {
-    return to_mcts(game, cfg, to_stub_eval, NULL, out);
+    return to_mcts(game, cfg, cfg->use_tanh ? to_stub_eval_tanh : to_stub_eval, NULL, out);
 }
 
 /* ---- play_game (ai.py:1570-1699) with the stub evaluator -----------------------------------------
@@ -424,6 +434,40 @@ int to_play_game(to_game *g, const to_mcts_config *cfg, to_eval_fn eval, void *c
                  uint16_t *child_moves, int *child_visits, int max_children_total, int *winner_out) {
     int plies = 0, ctot = 0, history = 1;
     to_mcts_result *res = (to_mcts_result *)malloc(sizeof(to_mcts_result));
+    if (cfg->random_start) {
+        /* ai.py:1588-1608: num_random_moves = np.random.exponential(0.04 * DIRICHLET_S) (engine draw: purpose 6,
+         * counter 0, -scale * log(u)); while it is > 0: a MAX_ITER = 1 search without playout cap, noise or forced
+         * playouts, then pick_random_move_by_policy (ai.py:999-1014): random.choices(moves, policies) over the root
+         * children's priors (engine draw: purpose 4, counter = ply).  Logged with save = 0 and nchild = 0. */
+        double left = -(0.04 * cfg->dir_s) * log(rng_unif(g->seed, g->stream, 6, 0));
+        to_mcts_config fast = *cfg;
+        fast.max_iter = 1; fast.use_playout_cap = 0; fast.use_dirichlet = 0; fast.use_forced = 0;
+        while (left > 0 && !to_is_terminal(g)) {
+            if (plies < max_log) to_export(g, &ply_state[plies]);
+            to_mcts(g, &fast, eval, ctx, res);
+            int n = res->n_root_children;
+            if (n <= 0) break;
+            int sel;
+            {   /* random.choices: itertools.accumulate, total = cum[-1] + 0.0, bisect_right(cum, x, 0, n - 1) */
+                double *cum = (double *)malloc(sizeof(double) * (size_t)n);
+                if (res->root_p_f32) { float a = 0; for (int k = 0; k < n; k++) { a = (k == 0) ? (float)res->root_p[0] : a + (float)res->root_p[k]; cum[k] = (double)a; } }
+                else { double a = 0; for (int k = 0; k < n; k++) { a = (k == 0) ? res->root_p[0] : a + res->root_p[k]; cum[k] = a; } }
+                double total = cum[n - 1] + 0.0;
+                double x = rng_unif(g->seed, g->stream, 4, g->ply) * total;
+                int lo = 0, hi = n - 1;
+                while (lo < hi) { int mid = (lo + hi) / 2; if (x < cum[mid]) hi = mid; else lo = mid + 1; }
+                sel = lo;
+                free(cum);
+            }
+            int mv = res->root_moves[sel];
+            if (plies < max_log) { ply_move[plies] = (uint16_t)mv; ply_save[plies] = 0; ply_nchild[plies] = 0; }
+            int mover = g->turn;
+            to_make_move(g, TRL_MOVE_PLANE(mv), TRL_MOVE_COL(mv) - 2, TRL_MOVE_ROW(mv), 1);
+            if (mover == 1 && g->turn == 0) history++;
+            plies++;
+            left -= 1;
+        }
+    }
     while (!to_is_terminal(g) && history < TRL_MAX_MOVES) {
         if (plies < max_log) to_export(g, &ply_state[plies]);
         to_mcts(g, cfg, eval, ctx, res);
@@ -446,6 +490,6 @@ int to_play_game(to_game *g, const to_mcts_config *cfg, to_eval_fn eval, void *c
 int to_play_game_stub(to_game *g, const to_mcts_config *cfg, int max_log, trl_game_state *ply_state, uint16_t *ply_move,
                       int *ply_save, int *ply_nchild, uint16_t *child_moves, int *child_visits, int max_children_total,
                       int *winner_out) {
-    return to_play_game(g, cfg, to_stub_eval, NULL, max_log, ply_state, ply_move, ply_save, ply_nchild, child_moves,
-                        child_visits, max_children_total, winner_out);
+    return to_play_game(g, cfg, cfg->use_tanh ? to_stub_eval_tanh : to_stub_eval, NULL, max_log, ply_state, ply_move, ply_save,
+                        ply_nchild, child_moves, child_visits, max_children_total, winner_out);
 }

@@ -8,3 +8,4 @@ mc = trl.AlphaSameConfig(blocks=10, filters=16)
 cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=160, training=True)
 sp = trl.SelfPlay(cfg, trl.AlphaSame(mc), 1024, seed=20260630, use_graph=True, record_capacity=65536)
 sp.tick(300); sp.synchronize()
+print("ticks done")

@@ -1,14 +1,18 @@
 """Summarise a rocprofv3 --pmc (+ --kernel-trace) csv output directory: per kernel name, launches, mean duration
-and the mean of every counter.  usage: python scripts/pmc_summary.py <dir> [name-filter]"""
+and the mean of every counter.  usage: python scripts/pmc_summary.py <dir> [name-filter] [--per-dispatch]"""
 import csv, glob, os, sys, collections
 
-d = sys.argv[1]
-flt = sys.argv[2] if len(sys.argv) > 2 else ""
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+per_dispatch = "--per-dispatch" in sys.argv
+d = args[0]
+flt = args[1] if len(args) > 1 else ""
 cnt = collections.defaultdict(lambda: collections.defaultdict(list))
+disp = collections.defaultdict(dict)
 dur = collections.defaultdict(list)
 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         cnt[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        disp[(r["Kernel_Name"], int(r["Dispatch_Id"]))][r["Counter_Name"]] = float(r["Counter_Value"])
         if "Start_Timestamp" in r and r.get("End_Timestamp"):
             dur[(r["Kernel_Name"], r["Dispatch_Id"])] = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
 for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
@@ -17,6 +21,16 @@ for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
 per = collections.defaultdict(list)
 for (k, _), v in dur.items():
     per[k].append(v)
+if per_dispatch:
+    for (k, i) in sorted(disp, key=lambda x: x[1]):
+        if flt and flt not in k:
+            continue
+        line = {"kernel": k[:40], "dispatch": i}
+        if (k, str(i)) in dur:
+            line["us"] = round(dur[(k, str(i))] / 1e3, 2)
+        line.update({c: v for c, v in sorted(disp[(k, i)].items())})
+        print(line)
+    sys.exit(0)
 for k in sorted(cnt):
     if flt and flt not in k:
         continue

@@ -39,6 +39,20 @@ def test_search_options_reject_what_the_device_lacks():
     with pytest.raises(ValueError):
         trl.search_options(trl.Config(move_algorithm="brute-force"))
     with pytest.raises(ValueError):
-        trl.search_options(trl.Config(use_tanh=True))
+        trl.search_options(trl.Config(FpuStrategy="nope"))
     o = trl.search_options(trl.Config(MAX_ITER=160, training=True))
     assert o.max_iter == 160 and o.training == 1 and o.use_playout_cap == 1 and abs(o.root_softmax_temp - 1.1) < 1e-12
+    assert o.use_tanh == 0 and o.random_start == 0
+    o = trl.search_options(trl.Config(use_tanh=True, use_random_starting_moves=True), episodes_base=3, episodes_extra=1)
+    assert o.use_tanh == 1 and o.random_start == 1 and (o.episodes_base, o.episodes_extra) == (3, 1)
+    c = trl.Config(use_tanh=True)
+    assert (c.value_min, c.value_mid, c.value_max, c.negate_value(0.25)) == (-1, 0, 1, -0.25)
+
+
+def test_seeds_are_fresh_or_derived():
+    from tetris_rl_amd import selfplay
+    a, b = selfplay.fresh_seed(), selfplay.fresh_seed()
+    assert a != b and 0 <= a < 2 ** 63
+    d = selfplay.derive_seed(7, "set", 3, 1)
+    assert d == selfplay.derive_seed(7, "set", 3, 1) and 0 <= d < 2 ** 63
+    assert len({selfplay.derive_seed(7, "set", n, 0) for n in range(50)} | {selfplay.derive_seed(7, "gate", n, 0, 1) for n in range(50)}) == 100

@@ -29,6 +29,38 @@ def test_game_object_follows_oracle():
     assert np.array_equal(c._pack(), g._pack())
 
 
+def _player_on_board(rows, piece_letter, held=None):
+    """tests.py:4-12 / 36-43: a fresh s1 game whose side to move gets `rows` as its board and `piece_letter` at spawn"""
+    g = trl.Game("s1", seed=7, stream=7)
+    g.setup()
+    pl = g.players[g.turn]
+    for r in range(40):
+        for c in range(10):
+            pl.board.grid[r][c] = 1 if (int(rows[r]) >> c) & 1 else 0
+    pl.piece = trl.compat.Piece(piece_letter)
+    pl.held_piece = held
+    return pl
+
+
+def test_reference_own_movegen_tests_through_compat(golden_dir):
+    """The reference's own tests of this path (tests.py:13-58), calls as the reference writes them: get_move_matrix with
+    its DEFAULT argument (= 'brute-force') finds 1..capacity moves on the four reference boards x 7 pieces, exactly 9 for
+    O on the empty board with O held, and algo='convolutional' gives the identical matrix on those boards."""
+    import os
+    d = np.load(os.path.join(golden_dir, "movegen.npz"))
+    boards = [d["rows"][i] for i in range(0, int(d["n_reference_cases"]) - 14, 14)]          # 4 boards x 7 pieces x 2 holds
+    assert len(boards) == 4
+    for rows in boards:
+        for letter in trl.compat.MINOS:
+            pl = _player_on_board(rows, letter)
+            bf = trl.get_move_matrix(pl)                                       # default argument
+            assert bf.shape == (27, 39, 11) and bf.dtype == bool and 1 <= int(bf.sum()) <= bf.size
+            assert np.array_equal(bf, trl.get_move_matrix(pl, algo="brute-force"))
+            assert np.array_equal(bf, trl.get_move_matrix(pl, algo="convolutional"))
+    pl = _player_on_board(np.zeros(40, dtype=np.uint16), "O", held="O")
+    assert int(trl.get_move_matrix(pl).sum()) == 9
+
+
 def test_unknown_algorithm_and_illegal_move():
     g = trl.Game("s1", seed=1)
     g.setup()

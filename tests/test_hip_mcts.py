@@ -307,3 +307,101 @@ def test_auto_reset_episodes_match_oracle_games():
             assert int(end[0]["winner"]) == o["winner"]
             checked += 1
     assert checked >= 2 * n
+
+
+def test_games_at_max_iter_160_tanh_and_random_start_match_reference(golden_dir):
+    """Whole reference play_game games replayed on the device (tests/golden/selfplay160.npz): two at BASELINE's
+    MAX_ITER=160 with training=True (playout cap 400 / 80 over a whole game, root noise, temperature pick: the C1 / C3
+    game loop), one with Config.use_tanh (value range -1..1), two with Config.use_random_starting_moves (one of them
+    without the root softmax: float32-typed priors in pick_random_move_by_policy).  Every ply: searched position, move,
+    save flag, root (move, N) vector; and the 13-field records hash to the reference's JSON."""
+    d = np.load(os.path.join(golden_dir, "selfplay160.npz"))
+    p_off = np.concatenate([[0], np.cumsum(d["game_plies"])])
+    c_off = np.concatenate([[0], np.cumsum(d["ply_child_counts"])])
+    r_off = np.concatenate([[0], np.cumsum(d["game_records"])])
+    for gi in range(d["game_ruleset"].shape[0]):
+        training, tanh = int(d["game_training"][gi]), int(d["game_use_tanh"][gi])
+        tag = str(d["game_tag"][gi])
+        eng = trl.Engine(1, ruleset="s1" if d["game_ruleset"][gi] == 1 else "s2", seed=int(d["seed"]))
+        eng.reset(np.array([d["game_stream"][gi]], dtype=np.uint32))
+        s = StubSearch(eng, trl.mcts_config(max_iter=int(d["game_max_iter"][gi]), training=training, save_all=int(not training),
+                                            auto_reset=0, use_tanh=tanh, random_start=int(d["game_random_start"][gi]),
+                                            use_root_softmax=int(d["game_root_softmax"][gi])))
+        recs = _play_until_done(eng, s, 420 * 130)
+        mv = recs[recs["kind"] == trl.REC_MOVE]
+        mv = mv[np.argsort(mv["ply"], kind="stable")]
+        end = recs[recs["kind"] == trl.REC_GAME_END]
+        assert len(end) == 1 and len(mv) == d["game_plies"][gi], tag
+        assert int(mv["random_move"].sum()) == d["game_n_rand"][gi] and mv["random_move"][:int(d["game_n_rand"][gi])].all(), tag
+        game_data = [[], []]
+        for k in range(len(mv)):
+            fk = p_off[gi] + k
+            a, b = mv[k]["state"].copy(), d["ply_state"][fk].copy()
+            a[304:308] = 0; b[304:308] = 0
+            assert np.array_equal(a, b), "searched position, %s ply %d" % (tag, k)
+            assert int(mv[k]["chosen"]) == d["ply_move"][fk], "%s ply %d" % (tag, k)
+            if mv[k]["random_move"]:
+                assert not mv[k]["saved"] and not mv[k]["visits"].any()
+                continue
+            n = int(mv[k]["n_children"])
+            assert int(mv[k]["saved"]) == (d["ply_save"][fk] or (not training))
+            assert np.array_equal(mv[k]["moves"][:n], d["ply_child_moves"][c_off[fk]:c_off[fk + 1]])
+            assert np.array_equal(mv[k]["visits"][:n].astype(np.int32), d["ply_child_visits"][c_off[fk]:c_off[fk + 1]])
+            if mv[k]["saved"]:
+                game_data[int(mv[k]["state"][312])] += records.records_for_move(mv[k]["state"], mv[k]["moves"][:n], mv[k]["visits"][:n])
+        vmin, vmid, vmax = (-1, 0, 1) if tanh else (0, 0.5, 1)
+        data = records.finish_game(game_data, int(end[0]["winner"]), vmin, vmid, vmax)
+        want = d["rec_hash"][r_off[gi]:r_off[gi + 1]]
+        assert len(data) == len(want), tag
+        for i, rec in enumerate(data):
+            assert hashlib.sha256(json.dumps(rec, separators=(",", ":")).encode()).hexdigest() == str(want[i]), tag
+
+
+def test_tanh_single_searches_match_reference(golden_dir):
+    """160-simulation reference searches with Config.use_tanh (ai.py:198-216: value_min -1, negate_value -v): root (move, N)
+    vectors, chosen move and save flag exact; then Q / P of the root children to 1e-12 on the eval-mode cases"""
+    d = np.load(os.path.join(golden_dir, "selfplay160.npz"))
+    off = np.concatenate([[0], np.cumsum(d["tanh_child_counts"])])
+    for vi in (0, 1):
+        idx = np.nonzero(d["tanh_variant"] == vi)[0]
+        eng = trl.Engine(len(idx), seed=int(d["seed"]))
+        eng.set_state(d["tanh_states"][idx])
+        s = StubSearch(eng, trl.mcts_config(max_iter=160, training=vi, auto_reset=0, use_tanh=1))
+        first = {}
+        for t in range(400):
+            s.tick()
+            for r in eng.mcts_drain_records():
+                if r["kind"] == trl.REC_MOVE and int(r["slot"]) not in first:
+                    first[int(r["slot"])] = r.copy()
+            if len(first) == len(idx):
+                break
+        assert len(first) == len(idx)
+        for j, ci in enumerate(idx):
+            r, sl = first[j], slice(off[ci], off[ci + 1])
+            n = int(r["n_children"])
+            assert np.array_equal(r["moves"][:n], d["tanh_child_moves"][sl])
+            assert np.array_equal(r["visits"][:n].astype(np.int32), d["tanh_child_visits"][sl])
+            assert int(r["chosen"]) == d["tanh_move"][ci] and int(r["saved"]) == d["tanh_save"][ci]
+    idx = np.nonzero(d["tanh_variant"] == 0)[0]
+    eng = trl.Engine(len(idx), seed=int(d["seed"]))
+    eng.set_state(d["tanh_states"][idx])
+    s = StubSearch(eng, trl.mcts_config(max_iter=161, training=0, auto_reset=0, use_tanh=1))
+    for t in range(160):
+        s.tick()
+    counts, moves, visits, q, p = eng.mcts_root_children()
+    for j, ci in enumerate(idx):
+        sl = slice(off[ci], off[ci + 1])
+        assert np.array_equal(visits[j, :counts[j]], d["tanh_child_visits"][sl])
+        assert np.allclose(q[j, :counts[j]], d["tanh_child_q"][sl], rtol=1e-12, atol=1e-15) and d["tanh_child_q"][sl].min() < 0
+        assert np.allclose(p[j, :counts[j]], d["tanh_child_p"][sl], rtol=1e-12, atol=1e-300)
+
+
+def test_search_limits_are_refused():
+    """a search too long for the record's uint16 visit counts, or more than 256 episodes per slot, is refused up front"""
+    eng = trl.Engine(4, ruleset="s2", seed=1)
+    eng.reset()
+    with pytest.raises(trl.EngineError):
+        eng.mcts_create(trl.mcts_config(max_iter=40000, training=1))           # long searches: 5 * 40000 / 2 > 65535
+    with pytest.raises(trl.EngineError):
+        eng.mcts_create(trl.mcts_config(max_iter=8, episodes_base=300))
+    eng.mcts_create(trl.mcts_config(max_iter=8, episodes_base=2, episodes_extra=1))

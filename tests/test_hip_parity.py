@@ -130,6 +130,40 @@ def test_movegen_cases(golden_dir):
     assert int(c1[0]) == 9
 
 
+def test_bruteforce_generator_and_t_piece_disagreements(golden_dir):
+    """Row M6: the device's 'brute-force' generator (trl_env_legal_moves_algo, the reference's default argument of
+    get_move_matrix) against the reference's brute-force lists -- movegen.npz where the fixture has them (incl. the
+    reference's own test boards) and all of movegen_t.npz: 240 T-piece positions where 'convolutional' and
+    'brute-force' DISAGREE + 120 where they agree; the convolutional lists of those too."""
+    d = _load(golden_dir, "movegen.npz")
+    idx = np.nonzero(d["has_brute"])[0]
+    states = np.stack([_state_for_case(d["rows"][i], int(d["piece"][i]), int(d["held"][i]), int(d["q0"][i])) for i in idx])
+    e = trl.Engine(len(idx), seed=SEED)
+    e.set_state(states)
+    cnt, mv = e.legal_moves("brute-force")
+    bc = np.concatenate([[0], np.cumsum(d["brute_counts"])])
+    for j, i in enumerate(idx):
+        assert np.array_equal(mv[j, :cnt[j]], d["brute_flat"][bc[i]:bc[i + 1]]), "movegen.npz case %d" % i
+    assert not (e.get_state()[:, 313] & 1).any()                      # no cap overflowed
+    t = _load(golden_dir, "movegen_t.npz")
+    n = t["rows"].shape[0]
+    assert int(t["differ"].sum()) >= 200
+    states = np.stack([_state_for_case(t["rows"][i], int(t["piece"][i]), int(t["held"][i]), int(t["q0"][i])) for i in range(n)])
+    e = trl.Engine(n, seed=SEED)
+    e.set_state(states)
+    cc = np.concatenate([[0], np.cumsum(t["conv_counts"])])
+    bc = np.concatenate([[0], np.cumsum(t["brute_counts"])])
+    cnt, mv = e.legal_moves("convolutional")
+    for i in range(n):
+        assert np.array_equal(mv[i, :cnt[i]], t["conv_flat"][cc[i]:cc[i + 1]]), "conv, T case %d" % i
+    cnt, mv = e.legal_moves("brute-force")
+    for i in range(n):
+        assert np.array_equal(mv[i, :cnt[i]], t["brute_flat"][bc[i]:bc[i + 1]]), "brute-force, T case %d" % i
+    assert not (e.get_state()[:, 313] & 1).any()
+    with pytest.raises(ValueError):
+        e.legal_moves("harddrop")                                      # not built: ValueError like an unknown name
+
+
 def test_uniform_games_from_seed_only(golden_dir):
     """the reference's uniform-policy games are reproduced by the fused rollout kernel from
     (seed, stream) alone -- bags, garbage columns and move choices all come from the RNG."""

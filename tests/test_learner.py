@@ -22,9 +22,8 @@ def _data(golden_dir, n=24):
     return g.records_from_fixture(n)
 
 
-@pytest.mark.parametrize("tag", ["alpha", "aux"])
-def test_one_epoch_matches_reference(golden_dir, tag, tmp_path, monkeypatch):
-    monkeypatch.setenv("TRL_STORAGE", str(tmp_path))
+def one_epoch_against_reference(golden_dir, tag, device):
+    """shared by the CPU test below and tests/test_hip_learner.py (the same step on the MI355X)"""
     d = np.load(os.path.join(golden_dir, "learner.npz"))
     if tag == "alpha":
         mc = nets.AlphaSameConfig(blocks=2, filters=8, dropout=0.0)
@@ -37,6 +36,7 @@ def test_one_epoch_matches_reference(golden_dir, tag, tmp_path, monkeypatch):
     sd = {k: (torch.from_numpy(w) if k == "policy_head.weight" else torch.from_numpy(b) if k == "policy_head.bias"
               else torch.from_numpy(d["%s/init/%s" % (tag, k)])) for k in net.state_dict().keys()}
     net.load_state_dict(sd)
+    net = net.to(device)
     cfg = trl.Config(visual=False, model="pytorch", model_config=mc, batch_size=8, shuffle=False, epochs=1,
                      learning_rate=0.001, weight_decay=0.01)
     entry = learner.train_network_pytorch(cfg, net, _data(golden_dir), data_number=0)
@@ -46,11 +46,17 @@ def test_one_epoch_matches_reference(golden_dir, tag, tmp_path, monkeypatch):
     after = net.state_dict()
     for k, v in after.items():
         ref = d["%s/after/%s" % (tag, k)]
-        mine = v.numpy()[ROWS_SAMPLED] if k.startswith("policy_head.") else v.numpy()
+        mine = v.cpu().numpy()[ROWS_SAMPLED] if k.startswith("policy_head.") else v.cpu().numpy()
         assert np.allclose(mine, ref, rtol=1e-4, atol=1e-5), k
-    assert os.path.isfile(tmp_path / "logs" / "training_log.jsonl")
     # the inference path sees the new weights (folded tensors are rebuilt)
     assert net._folded is None
+
+
+@pytest.mark.parametrize("tag", ["alpha", "aux"])
+def test_one_epoch_matches_reference(golden_dir, tag, tmp_path, monkeypatch):
+    monkeypatch.setenv("TRL_STORAGE", str(tmp_path))
+    one_epoch_against_reference(golden_dir, tag, "cpu")
+    assert os.path.isfile(tmp_path / "logs" / "training_log.jsonl")
 
 
 def test_packed_sets_train_exactly_like_the_json_sets(golden_dir, tmp_path, monkeypatch):
@@ -71,15 +77,20 @@ def test_packed_sets_train_exactly_like_the_json_sets(golden_dir, tmp_path, monk
         json.dump(lists, open("%s/%d.txt" % (cfg.data_dir, n), "w"))
         records.PackedSet.from_moves(packed, True).save("%s/%d.npz" % (learner.packed_dir(cfg), n))
     out = []
-    for use_packed in (True, False):
-        if not use_packed:
+    for use_packed in (True, "mixed", False):
+        if use_packed == "mixed":                 # set 1 only packed, sets 0 and 2 only in the reference's JSON format
+            os.remove("%s/1.txt" % cfg.data_dir)
+            os.remove("%s/0.npz" % learner.packed_dir(cfg)); os.remove("%s/2.npz" % learner.packed_dir(cfg))
+        if use_packed is False:
             shutil.rmtree(learner.packed_dir(cfg))
+            json.dump(_fixture_sets(golden_dir)[1][0], open("%s/1.txt" % cfg.data_dir, "w"))
         torch.manual_seed(3)
         net = nets.AlphaSame(mc)
         random.seed(11); torch.manual_seed(5)
         entry = learner.load_data_and_train_model(cfg, net)
         out.append((entry, {k: v.clone() for k, v in net.state_dict().items()}))
-    (e1, w1), (e2, w2) = out
-    assert e1["loss"] == e2["loss"] and e1["value_loss"] == e2["value_loss"] and e1["policy_loss"] == e2["policy_loss"]
+    (e1, w1), (em, wm), (e2, w2) = out
+    for e in (em, e2):
+        assert e1["loss"] == e["loss"] and e1["value_loss"] == e["value_loss"] and e1["policy_loss"] == e["policy_loss"]
     for k in w1:
-        assert torch.equal(w1[k], w2[k]), k
+        assert torch.equal(w1[k], w2[k]) and torch.equal(w1[k], wm[k]), k

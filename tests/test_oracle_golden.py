@@ -121,6 +121,22 @@ def test_movegen_reference_boards_and_samples(golden_dir):
             assert np.array_equal(brute, d["brute_flat"][bc[i]:bc[i + 1]]), "brute case %d" % i
 
 
+def test_movegen_t_piece_disagreements(golden_dir):
+    """H1 at depth: 240 T-piece positions where the reference's 'convolutional' and 'brute-force' lists differ (+120
+    where they agree); the oracle reproduces both lists on every one"""
+    d = _load(golden_dir, "movegen_t.npz")
+    cc = np.concatenate([[0], np.cumsum(d["conv_counts"])])
+    bc = np.concatenate([[0], np.cumsum(d["brute_counts"])])
+    assert int(d["differ"].sum()) >= 200
+    for i in range(d["rows"].shape[0]):
+        st = _state_for_case(d["rows"][i], int(d["piece"][i]), int(d["held"][i]), int(d["q0"][i]))
+        conv = op.mask_to_moves(op.move_matrix_from_state(st, 0, 0))
+        brute = op.mask_to_moves(op.move_matrix_from_state(st, 0, 1))
+        assert np.array_equal(conv, d["conv_flat"][cc[i]:cc[i + 1]]), "conv case %d" % i
+        assert np.array_equal(brute, d["brute_flat"][bc[i]:bc[i + 1]]), "brute case %d" % i
+        assert bool(d["differ"][i]) == (not np.array_equal(conv, brute))
+
+
 def test_reference_known_answers(golden_dir):
     """tests.py:23-32: O piece, held 'O', empty board -> exactly 9 placements (both algorithms);
     tests.py:45-58: convolutional == brute-force on the four reference boards."""

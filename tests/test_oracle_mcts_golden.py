@@ -73,3 +73,46 @@ def test_play_game_matches_reference(golden_dir):
         csl = slice(c_off[p_off[gi]], c_off[p_off[gi + 1]])
         assert np.array_equal(r["child_moves"], d["ply_child_moves"][csl])
         assert np.array_equal(r["child_visits"], d["ply_child_visits"][csl])
+
+
+def _cfg160(d, gi):
+    return op.default_mcts_config(max_iter=int(d["game_max_iter"][gi]), training=int(d["game_training"][gi]),
+                                  use_tanh=int(d["game_use_tanh"][gi]), random_start=int(d["game_random_start"][gi]),
+                                  use_root_softmax=int(d["game_root_softmax"][gi]))
+
+
+def test_play_game_160_tanh_and_random_start(golden_dir):
+    """whole reference games at MAX_ITER=160 with training=True (C1 / C3's game loop), a use_tanh game and two
+    use_random_starting_moves games (oracle/gen_golden_selfplay160.py): per-ply state, move, save flag, root vector"""
+    d = np.load(os.path.join(golden_dir, "selfplay160.npz"))
+    seed = int(d["seed"])
+    p_off = np.concatenate([[0], np.cumsum(d["game_plies"])])
+    c_off = np.concatenate([[0], np.cumsum(d["ply_child_counts"])])
+    assert d["game_n_rand"].sum() >= 2
+    for gi in range(d["game_ruleset"].shape[0]):
+        r = op.play_game_stub(int(d["game_ruleset"][gi]), seed, int(d["game_stream"][gi]), _cfg160(d, gi))
+        tag = str(d["game_tag"][gi])
+        assert r["plies"] == d["game_plies"][gi], tag
+        sl = slice(p_off[gi], p_off[gi + 1])
+        a, b = r["ply_state"].copy(), d["ply_state"][sl].copy()
+        a[:, 304:308] = 0; b[:, 304:308] = 0
+        assert np.array_equal(a, b), "pre-search states, " + tag
+        assert np.array_equal(r["ply_move"], d["ply_move"][sl]), tag
+        assert np.array_equal(r["ply_save"], d["ply_save"][sl]), tag
+        assert np.array_equal(r["ply_nchild"], d["ply_child_counts"][sl]), tag
+        csl = slice(c_off[p_off[gi]], c_off[p_off[gi + 1]])
+        assert np.array_equal(r["child_moves"], d["ply_child_moves"][csl]), tag
+        assert np.array_equal(r["child_visits"], d["ply_child_visits"][csl]), tag
+
+
+def test_mcts_tanh_searches(golden_dir):
+    d = np.load(os.path.join(golden_dir, "selfplay160.npz"))
+    off = np.concatenate([[0], np.cumsum(d["tanh_child_counts"])])
+    for i in range(d["tanh_states"].shape[0]):
+        cfg = op.default_mcts_config(training=int(d["tanh_variant"][i]), use_tanh=1)
+        r = op.mcts_stub(op.OracleGame(state=d["tanh_states"][i], seed=int(d["seed"])), cfg)
+        sl = slice(off[i], off[i + 1])
+        assert np.array_equal(r["moves"], d["tanh_child_moves"][sl]) and np.array_equal(r["visits"], d["tanh_child_visits"][sl])
+        assert r["move"] == d["tanh_move"][i] and r["save"] == d["tanh_save"][i]
+        assert np.array_equal(r["q"], d["tanh_child_q"][sl]) and np.array_equal(r["p"], d["tanh_child_p"][sl])
+        assert d["tanh_child_q"][sl].min() < 0                     # the negative half of the value range is exercised

@@ -24,7 +24,14 @@ def _worker(rank, world, port, q):
     elapsed, units = parallel.reduce_job(1.0 + rank, 100 * (rank + 1), dist)
     payload = np.arange(5 + 3 * rank, dtype=np.uint8) + rank
     got = parallel.gather_bytes(payload, dist)
-    q.put((rank, streams.tolist(), elapsed, units, None if got is None else [g.tolist() for g in got]))
+    # weight broadcast of the outer loop: every rank ends with rank 0's parameters and buffers
+    torch.manual_seed(100 + rank)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 3), torch.nn.BatchNorm1d(3))
+    net[1].num_batches_tracked.fill_(7 + rank)
+    parallel.broadcast_state_dict(net, dist)
+    digest = [float(v.double().sum()) for v in net.state_dict().values()]
+    ints = parallel.all_gather_ints([rank, 10 * rank + 1], dist).tolist()
+    q.put((rank, streams.tolist(), elapsed, units, None if got is None else [g.tolist() for g in got], digest, ints))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -47,6 +54,8 @@ def test_two_ranks_gloo():
         assert r[2] == 2.0 and r[3] == 300                                # max time, total units
     assert res[1][4] is None
     assert res[0][4] == [list(range(5)), [1 + i for i in range(8)]]
+    assert res[0][5] == res[1][5] and res[0][5][-1] == 7.0               # rank 0's weights (and its BN counter) everywhere
+    assert res[0][6] == res[1][6] == [[0, 1], [1, 11]]
 
 
 def test_single_process_paths():

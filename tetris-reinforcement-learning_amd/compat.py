@@ -151,16 +151,17 @@ class Game:
 
 
 def get_move_matrix(player, algo="brute-force"):
-    """move_generation.py:752-790.  The device implements the reference default 'convolutional'
-    (ai.py:84); any other name raises ValueError like the reference does for unknown algorithms."""
-    if algo != "convolutional":
+    """move_generation.py:752-790 with the reference's default argument: 'brute-force' (move_generation.py:204-243)
+    and 'convolutional' (:325-488, Config.move_algorithm's default, what the search uses) both run on the device.
+    The lossy 'faster-but-loss' / 'harddrop' generators are not built and raise ValueError like an unknown name."""
+    if algo not in _eng.MOVE_ALGORITHMS:
         raise ValueError("Unknown algorithm: %s" % algo)
     g = Game(player.ruleset)
     g.players[0] = player
     st = g._pack()
     e = _engine(player.ruleset, 0)
     e.set_state(st[None])
-    counts, moves = e.legal_moves()
+    counts, moves = e.legal_moves(algo)
     mask = np.zeros(POLICY_SHAPE, dtype=bool)
     for m in moves[0, :counts[0]]:
         m = int(m)

@@ -162,6 +162,49 @@ static __device__ unsigned long long g_prof[16];
 #define PROF_ADD(i, a, b)
 #endif
 
+// placements -> policy planes -> ascending move list (_convert_placements_to_policy, move_generation.py:650-749;
+// get_move_list order, ai.py:1016-1024).  S.present / S.flagp / S.ulp: per (rotation, row) the columns with an unflagged
+// placement / a rotation-flagged one / whose last flagged writer used the last kick.  One wavefront, lane = policy row.
+template <class SCR>
+static __device__ __forceinline__ int placements_to_moves(const SCR &S, int type, uint16_t *out, int out_cap, int lane) {
+    const bool isT = (type == PT);
+    int total = 0;
+    const int nrotp = C_NROT[type], base = C_PLANE_BASE[type];
+    const bool zsi = (type == PZ || type == PS || type == PI);
+    const int nts = isT ? 3 : 1;
+    for (int ts = 0; ts < nts; ts++) {
+        for (int ri = 0; ri < nrotp; ri++) {
+            uint32_t m = 0;
+            int row = lane;
+            if (row < TRL_POLICY_ROWS) {
+                auto src = [&](int o, int my) -> uint32_t {
+                    uint32_t p = S.present[o][my];
+                    if (!isT) return p;                                  // flagged placements are a subset (emit_flagged)
+                    uint32_t f = S.flagp[o][my], u = S.ulp[o][my];
+                    return ts == 0 ? (p & ~f) : (ts == 1 ? (f & ~u) : (f & u));
+                };
+                m = src(ri, row + 2);
+                if (zsi) {
+                    if (ri == 0) { if (row >= 1) m |= src(2, row + 1); }           // rot 2 -> rot 0, row + 1
+                    else m |= src(3, row + 2) >> 1;                                  // rot 3 -> rot 1, col - 1
+                }
+                m &= 0x7FFu;
+            }
+            int cnt = __popc(m);
+            int incl = wave_incl_scan(cnt, lane);
+            int off = total + incl - cnt;
+            int plane = base + ri + 4 * ts;
+            while (m) {
+                int c = __ffs((int)m) - 1; m &= m - 1;
+                if (off < out_cap) out[off] = (uint16_t)TRL_MOVE(plane, row, c);
+                off++;
+            }
+            total += __builtin_amdgcn_readlane(incl, 63);
+        }
+    }
+    return total;
+}
+
 // ---- the search: _generate_moves_for_piece + _convolutional_algorithm +
 //      _convert_placements_to_policy (move_generation.py:107-153, 325-488, 650-749) -----------
 // One wavefront.  rows: the player's 40 board rows in LDS.  `need_spawn` = the piece comes out of
@@ -325,40 +368,7 @@ static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int typ
         }
         PROF_T(c0);
 
-        // placements -> policy planes -> ascending move list (:650-749, ai.py:1016-1024)
-        const int nrotp = C_NROT[type], base = C_PLANE_BASE[type];
-        const bool zsi = (type == PZ || type == PS || type == PI);
-        const int nts = isT ? 3 : 1;
-        for (int ts = 0; ts < nts; ts++) {
-            for (int ri = 0; ri < nrotp; ri++) {
-                uint32_t m = 0;
-                int row = lane;
-                if (row < TRL_POLICY_ROWS) {
-                    auto src = [&](int o, int my) -> uint32_t {
-                        uint32_t p = S.present[o][my];
-                        if (!isT) return p;                                  // flagged placements are a subset (emit_flagged)
-                        uint32_t f = S.flagp[o][my], u = S.ulp[o][my];
-                        return ts == 0 ? (p & ~f) : (ts == 1 ? (f & ~u) : (f & u));
-                    };
-                    m = src(ri, row + 2);
-                    if (zsi) {
-                        if (ri == 0) { if (row >= 1) m |= src(2, row + 1); }           // rot 2 -> rot 0, row + 1
-                        else m |= src(3, row + 2) >> 1;                                  // rot 3 -> rot 1, col - 1
-                    }
-                    m &= 0x7FFu;
-                }
-                int cnt = __popc(m);
-                int incl = wave_incl_scan(cnt, lane);
-                int off = total + incl - cnt;
-                int plane = base + ri + 4 * ts;
-                while (m) {
-                    int c = __ffs((int)m) - 1; m &= m - 1;
-                    if (off < out_cap) out[off] = (uint16_t)TRL_MOVE(plane, row, c);
-                    off++;
-                }
-                total += __builtin_amdgcn_readlane(incl, 63);
-            }
-        }
+        total = placements_to_moves(S, type, out, out_cap, lane);
         if (total > out_cap) { *overflow = 1; total = out_cap; }
         PROF_T(c1); PROF_ADD(5, c0, c1);
     }
@@ -367,6 +377,104 @@ static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int typ
 #ifdef TRL_PROFILE
     if (lane == 0) for (int i = 0; i < 12; i++) atomicAdd(&g_prof[i], prof_acc[i]);
 #endif
+    return total;
+}
+
+// ---- the reference's default generator, 'brute-force' (move_generation.py:204-243) ------------------------------
+// A cell-by-cell FIFO search: pop a pose; already checked -> (if it cannot move down and this exact (pose, flags) is
+// not in the placement list yet, append it) and go on; else mark, append if it cannot move down, push right, left,
+// down (flags cleared), then the three rotations through Player.try_wallkick (player.py:77-102: first fitting kick;
+// only T sets the flags; new_y < 0 discarded).  The result differs from 'convolutional' only in which T-spin
+// sub-plane a placement lands in (the order in which flagged arrivals reach a cell).
+// Not a hot path (tests, get_move_matrix(player) with the reference's default argument): lane 0 of the wavefront
+// walks the queue, the lanes share the validity maps and the conversion to moves.
+constexpr int BF_QCAP = 10304;       // pushes happen on first visits only: 1 + 6 * (4 * 39 * 11) poses at most
+struct alignas(4) BfScratch {
+    uint16_t valid[4][MAP_H];
+    uint16_t checked[4][MAP_H];      // checked_list
+    uint16_t present[4][MAP_H];      // an unflagged placement is in the list
+    uint16_t flagp[4][MAP_H];        // a flagged one is
+    uint16_t ulp[4][MAP_H];          // the LAST flagged one appended used the last kick ("last flagged writer wins", :671-677)
+    uint16_t seen_fn[4][MAP_H];      // (flagged, no last kick) is in the list  -- `piece_location not in place_location_queue`
+    uint16_t seen_fl[4][MAP_H];      // (flagged, last kick) is in the list        compares the flags too (dataclass equality)
+    uint16_t queue[BF_QCAP];         // mx:4 | my:6 | rot:2 | flag:1 | last_kick:1
+};
+
+static __device__ __forceinline__ int movegen_bruteforce_wave(const uint16_t *rows, int type, bool need_spawn, BfScratch &S,
+                                                              uint16_t *out, int out_cap, int lane, int *overflow) {
+    for (int i = lane; i < 4 * MAP_H; i += 64) {
+        int r = i / MAP_H, ym = i - r * MAP_H;
+        S.valid[r][ym] = (uint16_t)valid_row(rows, type, r, ym);
+        S.checked[r][ym] = 0; S.present[r][ym] = 0; S.flagp[r][ym] = 0; S.ulp[r][ym] = 0; S.seen_fn[r][ym] = 0; S.seen_fl[r][ym] = 0;
+    }
+    uint64_t occ = __ballot(lane < TRL_ROWS && rows[lane < TRL_ROWS ? lane : 0] != 0);
+    int highest = occ ? (__ffsll((unsigned long long)occ) - 1) : TRL_ROWS;
+    int sy = highest - C_BOX[type]; if (sy < SPAWN_Y) sy = SPAWN_Y;
+    const int sx = spawn_x(type);
+    wave_sync();
+    bool ok = (S.valid[0][sy + 2] >> (sx + 2)) & 1;
+    if (need_spawn) ok = ok && ((S.valid[0][SPAWN_Y + 2] >> (sx + 2)) & 1);
+    ok = uni(ok);
+    int total = 0;
+    if (ok) {
+        if (lane == 0) {
+            auto fits = [&](int r, int mx, int my) -> bool {
+                return (unsigned)my < (unsigned)MAP_H && (unsigned)mx < 14u && ((S.valid[r][my] >> mx) & 1);
+            };
+            auto append = [&](int r, int mx, int my, int fl, int ul) {
+                const uint16_t bit = (uint16_t)(1u << mx);
+                if (!fl) S.present[r][my] |= bit;
+                else {
+                    S.flagp[r][my] |= bit;
+                    if (ul) { S.seen_fl[r][my] |= bit; S.ulp[r][my] |= bit; }
+                    else { S.seen_fn[r][my] |= bit; S.ulp[r][my] &= (uint16_t)~bit; }
+                }
+            };
+            const bool check_rot = (type != PO), isT = (type == PT);
+            const int ktab = (type == PI) ? 12 : 0;
+            int head = 0, tail = 1;
+            S.queue[0] = (uint16_t)((sx + 2) | ((sy + 2) << 4));
+            while (head < tail) {
+                const uint32_t it = S.queue[head++];
+                const int mx = it & 15, my = (it >> 4) & 63, rot = (it >> 10) & 3, fl = (it >> 12) & 1, ul = (it >> 13) & 1;
+                const uint16_t bit = (uint16_t)(1u << mx);
+                const bool down_ok = fits(rot, mx, my + 1);
+                if (S.checked[rot][my] & bit) {                                         // :212-217
+                    if (!down_ok) {
+                        const uint16_t have = !fl ? S.present[rot][my] : (ul ? S.seen_fl[rot][my] : S.seen_fn[rot][my]);
+                        if (!(have & bit)) append(rot, mx, my, fl, ul);
+                    }
+                    continue;
+                }
+                S.checked[rot][my] |= bit;
+                if (!down_ok) append(rot, mx, my, fl, ul);                              // :221-222
+                auto push = [&](int nmx, int nmy, int nrot, int nfl, int nul) {
+                    if (tail < BF_QCAP) S.queue[tail++] = (uint16_t)(nmx | (nmy << 4) | (nrot << 10) | (nfl << 12) | (nul << 13));
+                    else *overflow = 1;
+                };
+                if (fits(rot, mx + 1, my)) push(mx + 1, my, rot, 0, 0);                 // :225-232, in this order
+                if (fits(rot, mx - 1, my)) push(mx - 1, my, rot, 0, 0);
+                if (down_ok) push(mx, my + 1, rot, 0, 0);
+                if (check_rot)
+                    for (int dir = 1; dir <= 3; dir++) {                                // :235-243 + player.py:77-102
+                        const int nrot = (rot + dir) & 3;
+                        const uint64_t kt = C_KICK[ktab + rot * 3 + dir - 1];
+                        const int nk = (int)(kt >> 60);
+                        for (int ki = 0; ki < nk; ki++) {
+                            const int tx = mx - 2 + (int)((kt >> (6 * ki)) & 7), ty = my + 2 - (int)((kt >> (6 * ki + 3)) & 7);
+                            if (!fits(nrot, tx, ty)) continue;
+                            if (ty >= 2)                                                // new_location.y >= 0
+                                push(tx, ty, nrot, isT ? 1 : fl, isT ? ((ki == nk - 1 && dir != 2) ? 1 : 0) : ul);
+                            break;
+                        }
+                    }
+            }
+        }
+        wave_sync();
+        total = placements_to_moves(S, type, out, out_cap, lane);
+        if (total > out_cap) { *overflow = 1; total = out_cap; }
+    }
+    wave_sync();
     return total;
 }
 

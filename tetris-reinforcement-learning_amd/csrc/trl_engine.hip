@@ -42,6 +42,51 @@ __global__ __launch_bounds__(BLOCK, 8) void k_legal(trl_game_state *states, uint
     }
 }
 
+// get_move_matrix(player, 'brute-force') -- the reference's default argument (move_generation.py:752); row M6.
+struct BfBlockShared {
+    alignas(16) trl_game_state g;
+    BfScratch mg[2];
+    alignas(4) uint16_t list[2][TRL_MAX_LEGAL];
+    int cnt[2], order, overflow;
+};
+__global__ __launch_bounds__(BLOCK) void k_legal_bruteforce(trl_game_state *states, uint16_t *counts, uint16_t *moves) {
+    __shared__ BfBlockShared sh;
+    const int tid = threadIdx.x, game = blockIdx.x, wave = tid >> 6, lane = tid & 63;
+    {
+        const uint32_t *s = reinterpret_cast<const uint32_t *>(states + game);
+        uint32_t *d = reinterpret_cast<uint32_t *>(&sh.g);
+        if (tid < STATE_DW) d[tid] = s[tid];
+    }
+    if (tid == 0) { sh.overflow = 0; sh.cnt[0] = 0; sh.cnt[1] = 0; sh.order = 0; }
+    __syncthreads();
+    const trl_game_state &g = sh.g;
+    if (!is_terminal(g) && !no_move(g)) {
+        const trl_player_state &p = g.p[g.turn];
+        int t0, t1;
+        movegen_types(p, &t0, &t1);
+        const int type = wave == 0 ? t0 : t1;
+        if (type != P_NONE) {
+            int ovf = 0;
+            int n = movegen_bruteforce_wave(p.rows, type, wave == 1, sh.mg[wave], sh.list[wave], TRL_MAX_LEGAL, lane, &ovf);
+            if (lane == 0) { sh.cnt[wave] = n; if (ovf) sh.overflow = 1; }
+        }
+        if (tid == 0) {
+            int b0 = t0 != P_NONE ? C_PLANE_BASE[t0] : 99, b1 = t1 != P_NONE ? C_PLANE_BASE[t1] : 99;
+            sh.order = b1 < b0 ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    int total = sh.cnt[0] + sh.cnt[1];
+    if (total > TRL_MAX_LEGAL) { total = TRL_MAX_LEGAL; if (tid == 0) sh.overflow = 1; }
+    const int a = sh.order, na = sh.cnt[a];
+    for (int i = tid; i < total; i += BLOCK)
+        moves[(size_t)game * TRL_MAX_LEGAL + i] = i < na ? sh.list[a][i] : sh.list[1 - a][i - na];
+    if (tid == 0) {
+        counts[game] = (uint16_t)total;
+        if (sh.overflow) states[game].flags |= TRL_FLAG_OVERFLOW;
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_step(trl_game_state *states, const uint16_t *in_moves, uint64_t seed, int add_bag, int check_legal) {
     __shared__ BlockShared sh;
     const int tid = threadIdx.x, game = blockIdx.x;
@@ -301,12 +346,21 @@ int trl_env_legal_dev(trl_engine *h, void **dev_counts, void **dev_moves) {
 }
 
 int trl_env_legal_moves(trl_engine *h, uint16_t *host_counts, uint16_t *host_moves) {
+    return trl_env_legal_moves_algo(h, TRL_ALGO_CONVOLUTIONAL, host_counts, host_moves);
+}
+
+int trl_env_legal_moves_algo(trl_engine *h, int algo, uint16_t *host_counts, uint16_t *host_moves) {
     if (!h) return fail(TRL_E_INVALID, "%s", "null engine");
+    if (algo != TRL_ALGO_CONVOLUTIONAL && algo != TRL_ALGO_BRUTE_FORCE)
+        return fail(TRL_E_INVALID, "%s", "Unknown algorithm (the lossy generators 'faster-but-loss' / 'harddrop' are not built)");
     if (!h->have_reset) return fail(TRL_E_STATE, "%s", "trl_env_legal_moves before trl_env_reset / trl_env_set_state");
     HIPCHK(hipSetDevice(h->cfg.device));
     int n = h->cfg.n_games;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(k_legal, dim3(n), dim3(BLOCK), 0, h->stream, h->d_states, h->d_counts, h->d_moves);
+    if (algo == TRL_ALGO_BRUTE_FORCE)
+        hipLaunchKernelGGL(k_legal_bruteforce, dim3(n), dim3(BLOCK), 0, h->stream, h->d_states, h->d_counts, h->d_moves);
+    else
+        hipLaunchKernelGGL(k_legal, dim3(n), dim3(BLOCK), 0, h->stream, h->d_states, h->d_counts, h->d_moves);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     if (host_counts) HIPCHK(hipMemcpyAsync(host_counts, h->d_counts, (size_t)n * 2, hipMemcpyDeviceToHost, h->stream));

@@ -34,8 +34,9 @@ struct SlotCtl {
     int32_t n_nodes, n_states;
     int32_t leaf, leaf_kind, leaf_nlegal, leaf_state;
     int32_t overflow, leaf_parent_state;      // state index of the leaf's parent (-1 at the root)
-    int32_t depth, pad_;                      // nodes on the selection path root .. leaf (DevMcts::path)
-    double  terminal_value;
+    int32_t depth, random_move;               // nodes on the selection path root .. leaf (DevMcts::path); this search picks a
+    double  terminal_value;                   // random starting move (ai.py:1588-1608)
+    double  rand_left;                        // num_random_moves still to play in this game
 };
 constexpr int PATH_CAP = 64;                  // deeper paths are backed up by walking the parent links
 
@@ -161,8 +162,13 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
             for (int i = 0; i < 2; i++)
                 if (g.p[i].queue_len > TRL_PREVIEWS) { g.p[i].queue_len = TRL_PREVIEWS; g.p[i].queue &= (1ull << (4 * TRL_PREVIEWS)) - 1; }
             SlotCtl &c = sh.ctl;
-            c.fast = 0;
-            if (cfg.training && cfg.use_playout_cap) {                       // ai.py:322-330
+            c.fast = 0; c.random_move = 0;
+            if (cfg.random_start) {                                          // ai.py:1588-1608
+                if (g.ply == 0) c.rand_left = -(0.04 * cfg.dir_s) * log(rng_unif(M.seed, g.stream, 6, 0));
+                if (c.rand_left > 0) c.random_move = 1;
+            }
+            if (c.random_move) c.max_iter = 1;                               // fast_config: MAX_ITER = 1, no playout cap
+            else if (cfg.training && cfg.use_playout_cap) {                  // ai.py:322-330
                 double denom = cfg.playout_cap_chance * (cfg.playout_cap_mult - 1) + 1;
                 if (rng_unif(M.seed, g.stream, 3, g.ply) < cfg.playout_cap_chance)
                     c.max_iter = (int)ceil(cfg.playout_cap_mult * (cfg.max_iter / denom));
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
         }
         if (kind == 2) {
             int w = g.p[0].game_over ? 1 : (g.p[1].game_over ? 0 : -1);      // Game.winner, game.py:217-225
-            c.terminal_value = (w == g.turn) ? 1.0 : (w == 1 - g.turn) ? 0.0 : 0.5;
+            c.terminal_value = (w == g.turn) ? 1.0 : (w == 1 - g.turn) ? (cfg.use_tanh ? -1.0 : 0.0) : (cfg.use_tanh ? 0.0 : 0.5);
         }
         if (kind == 0 && sh.b.overflow) { c.overflow = 1; atomicAdd(&M.counters[5], 1ull); }     // a legal-move cap was hit
         M.ctl[slot] = c;
@@ -357,7 +363,8 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
     __syncthreads();
     if (sh.ctl.phase != 1) return;
     const int leaf = sh.ctl.leaf, kind = sh.ctl.leaf_kind;
-    const double value_min = 0.0;
+    const double value_min = cfg.use_tanh ? -1.0 : 0.0;                     // Config.value_min; negate_value below (ai.py:198-216)
+    const bool tanh_range = cfg.use_tanh != 0;
     if (MODE == 2 && kind != 2) {
         // complete z from the cache, store the leaf's entry, build x = [z_own, own extras, oside(z_opp), opp extras, colour]
         const float *z = policy, *vecp = values + (size_t)slot * TRL_VEC_FLOATS;
@@ -521,7 +528,8 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
             else { float s = 0.f; for (int k = 0; k < n; k++) s = s + sh.pf[k]; sh.red_f[0] = s; }
         }
         __syncthreads();
-        const double q0 = cfg.fpu_reduction ? fmax(value_min, 1.0 - value) : fmax(value_min, cfg.fpu_value);   // ai.py:447-453
+        const double q0 = cfg.fpu_reduction ? fmax(value_min, tanh_range ? -value : 1.0 - value)
+                                            : fmax(value_min, cfg.fpu_value);                                  // ai.py:447-453
         const double dsum = root_soft ? sh.dsum : 0.0;
         const float fsum = sh.red_f[0];
         for (int k = tid; k < n; k += BLOCK) {
@@ -542,7 +550,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
 
     // NOISE (ai.py:482-499): un-normalised gamma draws on the root's children
     MPROF_T(me2); MPROF_ADD(9, me1, me2);
-    if (cfg.training && !sh.ctl.fast && cfg.use_dirichlet && leaf == 0) {
+    if (cfg.training && !sh.ctl.fast && cfg.use_dirichlet && leaf == 0 && !sh.ctl.random_move) {
         const int n = M.t.nchild[nb], first = M.t.first[nb];
         if (n > 0) {
             double a = cfg.dir_alpha;
@@ -565,8 +573,8 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
     {
         // every node of the path gets the same two numbers, so the walk up the parent links (one dependent global
         // load per level) is replaced by one lane per level over the path k_select recorded
-        const double bval = 1.0 - value;
-        const double pos = bval, neg = 1.0 - bval;
+        const double bval = tanh_range ? -value : 1.0 - value;
+        const double pos = bval, neg = tanh_range ? -bval : 1.0 - bval;
         const int final_turn = M.t.turn[nb + leaf];
         const int depth = sh.ctl.depth;
         if (depth <= PATH_CAP) {
@@ -599,7 +607,8 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
                 float explored = 0.f; bool any = false;
                 for (int k = 0; k < n; k++)
                     if (sh.pf[k] >= 0.f) { explored = any ? explored + sh.pf[k] : sh.pf[k]; any = true; }
-                double fpu = (1.0 - M.t.q[nb + par]) - cfg.fpu_value * sqrt((double)explored);
+                const double qp = M.t.q[nb + par];
+                double fpu = (tanh_range ? -qp : 1.0 - qp) - cfg.fpu_value * sqrt((double)explored);
                 if (!(fpu > value_min)) fpu = value_min;
                 sh.dsum = fpu;
             }
@@ -621,7 +630,23 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
         if (tid == 0) {
             int sel = 0;
             const double temp = cfg.training ? cfg.temperature : 0.0;
-            if (n > 0) {
+            if (n > 0 && sh.ctl.random_move) {
+                // pick_random_move_by_policy (ai.py:999-1014): random.choices(moves, priors); float32-typed priors (no root
+                // softmax) accumulate in float32 as numpy scalars do
+                const bool f32 = M.t.pf32[nb + first] != 0;
+                float af = 0.f; double ad = 0.0;
+                for (int k = 0; k < n; k++) {
+                    const double pk = M.t.prior[nb + first + k];
+                    if (f32) { af = (k == 0) ? (float)pk : af + (float)pk; sh.pd[k] = (double)af; }
+                    else { ad = (k == 0) ? pk : ad + pk; sh.pd[k] = ad; }
+                }
+                const double total = sh.pd[n - 1] + 0.0;
+                const double x = rng_unif(M.seed, sh.g.stream, 4, sh.g.ply) * total;
+                int lo = 0, hi = n - 1;
+                while (lo < hi) { int mid = (lo + hi) / 2; if (x < sh.pd[mid]) hi = mid; else lo = mid + 1; }
+                sel = lo;
+                sh.ctl.rand_left -= 1.0;
+            } else if (n > 0) {
                 if (temp == 0.0) {                                             // np.argmax: first maximum
                     double best = -1.0;
                     for (int k = 0; k < n; k++) if (sh.pd[k] > best) { best = sh.pd[k]; sel = k; }
@@ -639,7 +664,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
             }
             sh.chosen = n > 0 ? (int)M.t.move[nb + first + sel] : -1;
             // policy-target pruning AFTER the move is chosen (ai.py:616-648): only the recorded visit counts change
-            if (cfg.use_forced && cfg.training && !sh.ctl.fast && n > 0) {
+            if (cfg.use_forced && cfg.training && !sh.ctl.fast && n > 0 && !sh.ctl.random_move) {
                 int max_n = 0, max_k = 0;
                 for (int k = 0; k < n; k++) { int v = M.t.visit[nb + first + k]; if (v >= max_n) { max_n = v; max_k = k; } }   // last maximum
                 const double rootN = (double)M.t.visit[nb], sq = sqrt(rootN);
@@ -679,7 +704,8 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
             if (tid == 0) {
                 r->slot = slot; r->episode = sh.g.episode; r->ply = sh.g.ply; r->n_children = (uint16_t)n;
                 r->kind = TRL_REC_MOVE; r->winner = -1; r->chosen = (uint16_t)sh.chosen;
-                r->saved = (uint8_t)((!sh.ctl.fast) || cfg.save_all); r->pad_ = 0;
+                r->saved = (uint8_t)(((!sh.ctl.fast) || cfg.save_all) && !sh.ctl.random_move);
+                r->random_move = (uint8_t)sh.ctl.random_move;
             }
         }
         __syncthreads();
@@ -708,12 +734,17 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
                     const trl_game_state &g = sh.g;
                     r->slot = slot; r->episode = g.episode; r->ply = g.ply; r->n_children = 0; r->kind = TRL_REC_GAME_END;
                     r->winner = (int8_t)(g.p[0].game_over ? 1 : (g.p[1].game_over ? 0 : -1));
-                    r->chosen = 0; r->saved = 0; r->pad_ = 0;
+                    r->chosen = 0; r->saved = 0; r->random_move = 0;
                 }
             }
             __syncthreads();
             if (tid == 0) {
-                if (cfg.auto_reset) {
+                const int quota = cfg.episodes_base + (slot < cfg.episodes_extra ? 1 : 0);      // 0: no limit
+                if (cfg.auto_reset && sh.g.episode + 1 >= 256u) {
+                    // the next episode's stream (+ 2^24 per episode) would wrap onto this slot's first one and replay its games
+                    sh.ctl.overflow = 1; atomicAdd(&M.counters[5], 1ull);
+                    sh.ctl.phase = 2;
+                } else if (cfg.auto_reset && !(quota > 0 && (int)sh.g.episode + 1 >= quota)) {
                     trl_game_state &g = sh.g;
                     uint32_t stream = g.stream + 0x01000000u, episode = g.episode + 1;
                     int ruleset = g.ruleset; uint8_t flags = g.flags;
@@ -787,7 +818,10 @@ __global__ __launch_bounds__(256) void k_stub_eval(DevMcts M, float *values, flo
     }
     h = mix64(h ^ s->turn);
     if (salt) h = mix64(h ^ salt);
-    if (tid == 0) values[slot] = (float)(mix64(h) >> 40) * (1.0f / 16777216.0f);
+    if (tid == 0) {
+        const float v = (float)(mix64(h) >> 40) * (1.0f / 16777216.0f);
+        values[slot] = M.cfg.use_tanh ? 2.0f * v - 1.0f : v;                // tanh-range stub (oracle: to_stub_eval_tanh)
+    }
     for (int i = tid; i < TRL_POLICY_SIZE; i += blockDim.x) {
         uint64_t k = mix64(h ^ ((uint64_t)(i + 1) * 0x9E3779B97F4A7C15ull));
         float u = (float)(k >> 40) * (1.0f / 16777216.0f);
@@ -868,6 +902,14 @@ int trl_mcts_create(trl_engine *h, const trl_mcts_config *cfg) {
         double denom = cfg->playout_cap_chance * (cfg->playout_cap_mult - 1) + 1;
         longest = (int)ceil(cfg->playout_cap_mult * (cfg->max_iter / denom));
         if (longest < cfg->max_iter) longest = cfg->max_iter;
+    }
+    if (longest > 65535) {                         // trl_record.visits is uint16: the longest search must fit
+        delete m;
+        return fail(TRL_E_INVALID, "trl_mcts_create: %s", "searches longer than 65535 simulations do not fit the record's visit counts");
+    }
+    if (cfg->episodes_base < 0 || cfg->episodes_extra < 0 || cfg->episodes_base + (cfg->episodes_extra > 0) > 256) {
+        delete m;
+        return fail(TRL_E_INVALID, "trl_mcts_create: %s", "at most 256 episodes per slot (RNG stream = slot stream + episode * 2^24)");
     }
     d.cap_states = longest + 2;
     // default tree capacity: one expansion per simulation, ~50 children each (measured: 20.5 k nodes after 400
@@ -966,6 +1008,21 @@ int trl_mcts_drain_records(trl_engine *h, trl_record *host_out, int cap, int *n_
     if (cnt) HIPCHK(hipMemcpyAsync(host_out, d.recs, (size_t)cnt * sizeof(trl_record), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipMemsetAsync(d.rec_count, 0, 4, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    *n_out = (int)cnt;
+    return TRL_OK;
+}
+
+int trl_mcts_drain_records_dev(trl_engine *h, trl_record *dev_out, int cap, int *n_out) {
+    if (!h || !h->mcts || !dev_out || !n_out || cap < 0) return fail(TRL_E_INVALID, "trl_mcts_drain_records_dev: %s", "bad argument");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    DevMcts &d = h->mcts->d;
+    unsigned int cnt = 0;
+    HIPCHK(hipMemcpyAsync(&cnt, d.rec_count, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (cnt > (unsigned)d.rec_cap) cnt = (unsigned)d.rec_cap;
+    if ((int)cnt > cap) return fail(TRL_E_OVERFLOW, "trl_mcts_drain_records_dev: %s", "buffer smaller than the pending records");
+    if (cnt) HIPCHK(hipMemcpyAsync(dev_out, d.recs, (size_t)cnt * sizeof(trl_record), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(d.rec_count, 0, 4, h->stream));
     *n_out = (int)cnt;
     return TRL_OK;
 }

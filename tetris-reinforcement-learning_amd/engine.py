@@ -14,14 +14,15 @@ STATE_BYTES = 320
 MAX_LEGAL = 512
 MOVE_NONE = 0xFFFF
 RULESETS = {"s1": 1, "s2": 2}
+MOVE_ALGORITHMS = {"convolutional": 0, "brute-force": 1}
 
 # every symbol include/tetris_engine.h declares (tests/test_abi.py checks the header against this)
 ABI_SYMBOLS = [
     "trl_engine_create", "trl_engine_destroy", "trl_set_stream", "trl_last_error", "trl_version",
     "trl_env_reset", "trl_env_get_state", "trl_env_set_state", "trl_env_state_dev",
-    "trl_env_legal_moves", "trl_env_legal_dev", "trl_env_step", "trl_env_step_dev",
+    "trl_env_legal_moves", "trl_env_legal_moves_algo", "trl_env_legal_dev", "trl_env_step", "trl_env_step_dev",
     "trl_env_rollout_random", "trl_last_kernel_ms",
-    "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_expand_head", "trl_mcts_drain_records", "trl_mcts_get_stats",
+    "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_expand_head", "trl_mcts_drain_records", "trl_mcts_drain_records_dev", "trl_mcts_get_stats",
     "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16", "trl_alphasame_trunk16_need", "trl_alphasame_trunk", "trl_resnet_trunk", "trl_graph_begin", "trl_graph_end", "trl_graph_launch",
     "trl_mcts_select_need", "trl_mcts_expand_alphasame_masked", "trl_mcts_zcache", "trl_mcts_zcache_dim", "trl_mcts_expand_alphasame",
 ]
@@ -37,7 +38,8 @@ class TrlMctsConfig(C.Structure):
                 ("use_root_softmax", C.c_int32), ("use_playout_cap", C.c_int32), ("use_dirichlet", C.c_int32),
                 ("use_dir_s", C.c_int32), ("use_forced", C.c_int32), ("save_all", C.c_int32),
                 ("max_nodes", C.c_int32), ("record_capacity", C.c_int32), ("auto_reset", C.c_int32),
-                ("cpuct", C.c_double), ("dpuct", C.c_double), ("fpu_value", C.c_double),
+                ("use_tanh", C.c_int32), ("random_start", C.c_int32), ("episodes_base", C.c_int32),
+                ("episodes_extra", C.c_int32), ("cpuct", C.c_double), ("dpuct", C.c_double), ("fpu_value", C.c_double),
                 ("root_softmax_temp", C.c_double), ("temperature", C.c_double),
                 ("playout_cap_chance", C.c_double), ("playout_cap_mult", C.c_double),
                 ("dir_alpha", C.c_double), ("dir_s", C.c_double), ("dir_expl", C.c_double), ("c_forced", C.c_double)]
@@ -46,7 +48,7 @@ class TrlMctsConfig(C.Structure):
 def mcts_config(**kw):
     c = TrlMctsConfig(max_iter=400, training=0, fpu_reduction=1, use_root_softmax=1, use_playout_cap=1,
                       use_dirichlet=1, use_dir_s=1, use_forced=0, save_all=0, max_nodes=0, record_capacity=0,
-                      auto_reset=1, cpuct=0.75, dpuct=1.0, fpu_value=0.1, root_softmax_temp=1.1, temperature=0.1,
+                      auto_reset=1, use_tanh=0, random_start=0, episodes_base=0, episodes_extra=0, cpuct=0.75, dpuct=1.0, fpu_value=0.1, root_softmax_temp=1.1, temperature=0.1,
                       playout_cap_chance=0.25, playout_cap_mult=5.0, dir_alpha=0.1, dir_s=25.0, dir_expl=0.25,
                       c_forced=1.0)
     for k, v in kw.items():
@@ -57,7 +59,7 @@ def mcts_config(**kw):
 
 
 RECORD_DTYPE = np.dtype([("slot", "<u4"), ("episode", "<u4"), ("ply", "<u4"), ("n_children", "<u2"), ("kind", "u1"),
-                         ("winner", "i1"), ("chosen", "<u2"), ("saved", "u1"), ("pad_", "u1"), ("pad2_", "<u4"),
+                         ("winner", "i1"), ("chosen", "<u2"), ("saved", "u1"), ("random_move", "u1"), ("pad2_", "<u4"),
                          ("state", "u1", (320,)), ("moves", "<u2", (512,)), ("visits", "<u2", (512,))])
 assert RECORD_DTYPE.itemsize == 2392
 REC_MOVE, REC_GAME_END = 0, 1
@@ -112,6 +114,7 @@ def load_library(path=None):
     L.trl_env_set_state.argtypes = [C.c_void_p, C.c_void_p]
     L.trl_env_state_dev.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
     L.trl_env_legal_moves.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.trl_env_legal_moves_algo.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.trl_env_legal_dev.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.trl_env_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.trl_env_step_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
@@ -122,6 +125,7 @@ def load_library(path=None):
     L.trl_mcts_expand.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.trl_mcts_expand_head.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.trl_mcts_drain_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.trl_mcts_drain_records_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.trl_mcts_get_stats.argtypes = [C.c_void_p, C.POINTER(TrlMctsStats)]
     L.trl_mcts_leaf_states.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.trl_mcts_root_children.argtypes = [C.c_void_p] + [C.c_void_p] * 5
@@ -204,10 +208,15 @@ class Engine:
             raise ValueError("states must have shape (n_games, %d)" % STATE_BYTES)
         _check(self._L, self._L.trl_env_set_state(self._h, states.ctypes.data), "trl_env_set_state")
 
-    def legal_moves(self):
+    def legal_moves(self, algo="convolutional"):
+        """algo: 'convolutional' (Config.move_algorithm's default, what the search uses) or 'brute-force'
+        (get_move_matrix's default argument); anything else raises ValueError as the reference does"""
+        if algo not in MOVE_ALGORITHMS:
+            raise ValueError("Unknown algorithm: %s" % algo)
         counts = np.empty(self.n_games, dtype=np.uint16)
         moves = np.empty((self.n_games, MAX_LEGAL), dtype=np.uint16)
-        _check(self._L, self._L.trl_env_legal_moves(self._h, counts.ctypes.data, moves.ctypes.data), "trl_env_legal_moves")
+        _check(self._L, self._L.trl_env_legal_moves_algo(self._h, MOVE_ALGORITHMS[algo], counts.ctypes.data, moves.ctypes.data),
+               "trl_env_legal_moves_algo")
         return counts, moves
 
     def step(self, moves, add_bag=True, check_legal=True):
@@ -287,6 +296,12 @@ class Engine:
         _check(self._L, self._L.trl_mcts_drain_records(self._h, buf.ctypes.data, self._rec_cap, C.byref(n)),
                "trl_mcts_drain_records")
         return buf[:n.value].copy()
+
+    def mcts_drain_records_dev(self, dev_ptr, cap):
+        """pending records -> device buffer at dev_ptr (room for `cap` records); returns the count"""
+        n = C.c_int(0)
+        _check(self._L, self._L.trl_mcts_drain_records_dev(self._h, dev_ptr, int(cap), C.byref(n)), "trl_mcts_drain_records_dev")
+        return n.value
 
     def mcts_stats(self):
         st = TrlMctsStats()

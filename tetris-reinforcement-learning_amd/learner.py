@@ -158,51 +158,74 @@ def packed_dir(config):
     return config.data_dir.rstrip("/") + "_packed"
 
 
-def _load_packed(config, names):
-    """the sets `names` as records.PackedSet objects if every one has its packed file, else None"""
+def _load_sets(config, names):
+    """every set of `names` in its cheapest available form: ("packed", records.PackedSet) when the packed file exists,
+    else ("json", list of 13-field records) from the reference-format file (sets written by the reference itself, or
+    before this build kept packed copies)"""
     from . import records
     out = []
     for name in names:
         path = "%s/%s.npz" % (packed_dir(config), name.split(".")[0])
-        if not os.path.isfile(path):
-            return None
-        out.append(records.PackedSet.load(path))
+        if os.path.isfile(path):
+            out.append(("packed", records.PackedSet.load(path)))
+        else:
+            with open("%s/%s" % (config.data_dir, name)) as f:
+                out.append(("json", json.load(f)))
     return out
+
+
+_FIELD_DTYPES = [np.float32, np.float32, np.int64, np.int64, np.int64, np.float32, np.float32, np.int64, np.int64, np.int64,
+                 np.int64, np.float64, np.float32]
+
+
+def _features_of_records(recs):
+    """the 13 feature arrays (dtypes of records.PackedSet.features) of reference-format records"""
+    if not recs:
+        return None
+    return [np.array([r[f] for r in recs], dtype=_FIELD_DTYPES[f]) for f in range(13)]
 
 
 def load_data_and_train_model(config, model, data=None):
     """ai.py:1871-1921, 'merge' style: newer sets are sampled fully, older ones with decay_factor ** age.
-    When every set has its packed form the records are never materialised as lists: the same random.sample /
-    random.shuffle draws are made over record indices and the feature arrays are built for the chosen records."""
+    Sets that have a packed copy are never materialised as lists: the same random.sample / random.shuffle draws are made
+    over record indices (random.sample draws positions, so sampling range(n) consumes the generator exactly as sampling
+    the n records does) and the feature arrays are built for the chosen records; sets that exist only in the reference's
+    JSON format are read as the reference reads them -- set by set, so the two kinds mix."""
     if config.data_loading_style != "merge":
         raise NotImplementedError
     if data is None:
-        data = []
         names = sorted(get_data_filenames(config), key=lambda x: int(x.split(".")[0]), reverse=True)
-        packed = _load_packed(config, names) if names else None
-        if packed is not None:
+        sets = _load_sets(config, names)
+        if all(kind == "json" for kind, _ in sets):              # the reference's own path, statement for statement
+            data = []
+            for age, (_, s) in enumerate(sets):
+                data.extend(random.sample(s, int(len(s) * config.decay_factor ** age)))
+        else:
             picks = []                                           # (set index, record index) in the reference's order
-            for age, ps in enumerate(packed):
-                n = len(ps)
+            for age, (_, s) in enumerate(sets):
+                n = len(s)
                 picks.extend((age, j) for j in random.sample(range(n), int(n * config.decay_factor ** age)))
             if config.shuffle:
                 random.shuffle(picks)
-            parts = {a: ps.features(np.array([j for aa, j in picks if aa == a], dtype=np.int64)) for a, ps in enumerate(packed)}
+            parts = {}
+            for a, (kind, s) in enumerate(sets):
+                idx = [j for aa, j in picks if aa == a]
+                if not idx:
+                    continue
+                parts[a] = s.features(np.array(idx, dtype=np.int64)) if kind == "packed" else \
+                    _features_of_records([s[j] for j in idx])
             where, counters = np.zeros((len(picks), 2), dtype=np.int64), {a: 0 for a in parts}
             for k, (a, _) in enumerate(picks):
                 where[k] = (a, counters[a]); counters[a] += 1
+            first = parts[next(iter(parts))]
             feats = []
             for f in range(13):
-                arr = np.empty((len(picks),) + parts[0][f].shape[1:], dtype=parts[0][f].dtype)
+                arr = np.empty((len(picks),) + first[f].shape[1:], dtype=first[f].dtype)
                 for a in parts:
                     sel = where[:, 0] == a
                     arr[sel] = parts[a][f][where[sel, 1]]
                 feats.append(arr)
             return train_network_pytorch(config, model, tuple(feats))
-        for age, name in enumerate(names):
-            with open("%s/%s" % (config.data_dir, name)) as f:
-                s = json.load(f)
-            data.extend(random.sample(s, int(len(s) * config.decay_factor ** age)))
     else:
         data = [x for s in data for x in s]
     if config.shuffle:

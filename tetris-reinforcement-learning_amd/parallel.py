@@ -2,7 +2,8 @@
 
 Self-play games are independent (ai.py:1817-1820, 1854-1860), so the env / search path has no
 collective; torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests) is used
-for the barrier, for timing reductions and for gathering training records to rank 0.
+for the barrier, for timing reductions, for gathering training records to rank 0 and for
+broadcasting promoted weights.
 """
 import os
 
@@ -13,6 +14,10 @@ def dist_env():
     """(rank, local_rank, world_size) from the torchrun environment (1 process: 0, 0, 1)."""
     return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
             int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def active(dist):
+    return dist is not None and dist.is_initialized() and dist.get_world_size() > 1
 
 
 def game_streams(rank, games_per_rank, episode_base=0):
@@ -27,7 +32,7 @@ def game_streams(rank, games_per_rank, episode_base=0):
 
 def reduce_job(elapsed_s, units, dist=None, device=None):
     """Whole-job numbers from per-rank ones: max elapsed time, total units processed."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if not active(dist):
         return float(elapsed_s), int(units)
     import torch
     t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
@@ -37,26 +42,75 @@ def reduce_job(elapsed_s, units, dist=None, device=None):
     return float(t.item()), int(u.item())
 
 
-def gather_bytes(payload, dist=None, device=None, dst=0):
-    """Gather one variable-length uint8 array per rank to `dst` (all_gather of lengths, then a
-    padded gather) -- the exchange step for packed training records.  Returns the list of
-    per-rank arrays on `dst`, None elsewhere."""
-    payload = np.ascontiguousarray(payload, dtype=np.uint8).reshape(-1)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return [payload]
+def all_gather_ints(values, dist, device=None):
+    """every rank's small tuple of ints on every rank: int64 [world, len(values)] as a numpy array"""
+    import torch
+    mine = torch.tensor([int(v) for v in values], dtype=torch.int64, device=device)
+    out = torch.empty(dist.get_world_size() * mine.numel(), dtype=torch.int64, device=device)     # flat: gloo insists
+    dist.all_gather_into_tensor(out, mine)
+    return out.cpu().numpy().reshape(dist.get_world_size(), mine.numel())
+
+
+def gather_tensor(payload, sizes, dist, dst=0):
+    """The exchange step of the path: one variable-length uint8 tensor per rank -> list of per-rank tensors on `dst`,
+    None elsewhere.  `payload` lives where the backend works (HBM for RCCL: the records go GPU -> GPU over xGMI and
+    never touch the sender's host; host memory for gloo); `sizes[r]` = bytes of rank r (from all_gather_ints).  A padded
+    dist.gather: only `dst` receives anything."""
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
-    n = torch.tensor([payload.size], dtype=torch.int64, device=device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
-    cap = max(max(sizes), 1)
-    buf = torch.zeros(cap, dtype=torch.uint8, device=device)
-    if payload.size:
-        buf[:payload.size] = torch.from_numpy(payload).to(buf.device)
-    # all_gather is used instead of gather: RCCL and gloo both implement it for every dtype
-    out = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf)
+    cap = int(max(max(sizes), 1))
+    if payload.numel() == cap:
+        buf = payload
+    else:
+        buf = torch.empty(cap, dtype=torch.uint8, device=payload.device)
+        buf[:payload.numel()] = payload
+    out = [torch.empty(cap, dtype=torch.uint8, device=payload.device) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, out, dst=dst)
     if rank != dst:
         return None
-    return [o[:s].cpu().numpy() for o, s in zip(out, sizes)]
+    return [o[:int(s)] for o, s in zip(out, sizes)]
+
+
+def gather_bytes(payload, dist=None, device=None, dst=0):
+    """gather_tensor for a numpy uint8 array per rank (lengths exchanged first).  Returns the list of per-rank
+    arrays on `dst`, None elsewhere."""
+    payload = np.ascontiguousarray(payload, dtype=np.uint8).reshape(-1)
+    if not active(dist):
+        return [payload]
+    import torch
+    sizes = all_gather_ints([payload.size], dist, device)[:, 0]
+    t = torch.from_numpy(payload)
+    if device is not None:
+        t = t.to(device)
+    parts = gather_tensor(t, sizes, dist, dst)
+    if parts is None:
+        return None
+    return [p.cpu().numpy() for p in parts]
+
+
+def broadcast_state_dict(module, dist, src=0):
+    """rank `src`'s parameters and buffers to every rank, in place (the refreshed weights of the outer loop,
+    SURVEY.md section 8e: one flat bucket, one broadcast -- 24 MB for AlphaSame(10, 16))"""
+    if not active(dist):
+        return module
+    import torch
+    tensors = [t for t in module.state_dict().values() if t.is_floating_point()]
+    others = [t for t in module.state_dict().values() if not t.is_floating_point()]
+    host = dist.get_backend() != "nccl"           # gloo moves host memory
+    if tensors:
+        flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in tensors])
+        if host:
+            flat = flat.cpu()
+        dist.broadcast(flat, src=src)
+        off = 0
+        with torch.no_grad():
+            for t in tensors:
+                n = t.numel()
+                t.copy_(flat[off:off + n].reshape(t.shape).to(t.dtype))
+                off += n
+    for t in others:                         # num_batches_tracked counters
+        b = t.cpu() if host else t
+        dist.broadcast(b, src=src)
+        if b is not t:
+            t.copy_(b)
+    return module

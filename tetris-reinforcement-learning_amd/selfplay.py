@@ -84,20 +84,17 @@ class Config:
 def search_options(config, **extra):
     """Config -> trl_mcts_config"""
     if config.move_algorithm != "convolutional":
-        raise ValueError("Unknown algorithm: %s (the device implements the reference default 'convolutional')"
-                         % config.move_algorithm)
-    if config.use_tanh:
-        raise ValueError("use_tanh=True is not supported by the device search (value range [0, 1] only)")
+        raise ValueError("Unknown algorithm: %s (the search runs the reference default 'convolutional'; 'brute-force' is "
+                         "available through get_move_matrix)" % config.move_algorithm)
     if config.FpuStrategy not in ("reduction", "absolute"):
         raise ValueError("Unknown FpuStrategy: %s" % config.FpuStrategy)
-    if config.use_random_starting_moves:
-        raise ValueError("use_random_starting_moves is not supported by the device driver")
     opts = dict(max_iter=int(config.MAX_ITER), training=int(bool(config.training)),
                 fpu_reduction=int(config.FpuStrategy == "reduction"), use_root_softmax=int(bool(config.use_root_softmax)),
                 use_playout_cap=int(bool(config.use_playout_cap_randomization)),
                 use_dirichlet=int(bool(config.use_dirichlet_noise)), use_dir_s=int(bool(config.use_dirichlet_s)),
                 use_forced=int(bool(config.use_forced_playouts_and_policy_target_pruning)),
-                save_all=int(bool(config.save_all)), cpuct=float(config.CPUCT), dpuct=float(config.DPUCT),
+                save_all=int(bool(config.save_all)), use_tanh=int(bool(config.use_tanh)),
+                random_start=int(bool(config.use_random_starting_moves)), cpuct=float(config.CPUCT), dpuct=float(config.DPUCT),
                 fpu_value=float(config.FpuValue), root_softmax_temp=float(config.RootSoftmaxTemp),
                 temperature=float(config.temperature), playout_cap_chance=float(config.playout_cap_chance),
                 playout_cap_mult=float(config.playout_cap_mult), dir_alpha=float(config.DIRICHLET_ALPHA),
@@ -107,12 +104,26 @@ def search_options(config, **extra):
     return _eng.mcts_config(**opts)
 
 
+def fresh_seed():
+    """The reference plays on CPython's global generator, seeded from the OS: every set and every match sees fresh
+    randomness.  Here a run is a function of (seed, stream), so a seed that is not given is drawn from the OS."""
+    return int.from_bytes(os.urandom(8), "little") >> 1
+
+
+def derive_seed(base, *parts):
+    """a reproducible seed per (base seed, set number, model number, purpose): a resumed loop does not replay the games
+    of an earlier set, and successive gating matches do not share their piece / garbage streams"""
+    import hashlib
+    h = hashlib.blake2b(repr((int(base),) + tuple(parts)).encode(), digest_size=8).digest()
+    return int.from_bytes(h, "little") >> 1
+
+
 # ---- the tick loop ----------------------------------------------------------------------------------------
 class SelfPlay:
     """n_slots concurrent self-play games: Engine + net + HIP-graph tick."""
 
     def __init__(self, config, network, n_slots, seed=0, device=0, streams=None, auto_reset=True, use_graph=True,
-                 max_nodes=0, record_capacity=0, policy_head="legal", tower_cache=True, device_heads=True):
+                 max_nodes=0, record_capacity=0, policy_head="legal", tower_cache=True, device_heads=True, episodes=(0, 0)):
         """policy_head: "legal" = only the legal moves' logits are formed, inside the expand kernel
         (trl_mcts_expand_head); "full" = the reference's data flow, softmax over all 11 583 logits."""
         if policy_head not in ("legal", "full"):
@@ -129,8 +140,11 @@ class SelfPlay:
         self.stream = torch.cuda.Stream(device=self.device)
         self.engine = _eng.Engine(self.n, ruleset=config.ruleset, seed=seed, device=device, stream=self.stream.cuda_stream)
         self.engine.reset(streams)
+        # episodes = (base, extra): slot s plays base + (s < extra) games, then idles (0, 0: no limit)
         self.engine.mcts_create(search_options(config, auto_reset=int(bool(auto_reset)), max_nodes=max_nodes,
-                                               record_capacity=record_capacity))
+                                               record_capacity=record_capacity, episodes_base=int(episodes[0]),
+                                               episodes_extra=int(episodes[1])))
+        self._rec_dev = None
         with torch.cuda.stream(self.stream):
             self.grids = torch.zeros((2, self.n, _eng.GRID_FLOATS), dtype=torch.float32, device=self.device)
             self.vec = torch.zeros((self.n, _eng.VEC_FLOATS), dtype=torch.float32, device=self.device)
@@ -217,6 +231,16 @@ class SelfPlay:
         self.stream.synchronize()
         return self.engine.mcts_drain_records()
 
+    def drain_dev(self):
+        """pending records as a uint8 tensor in HBM (n * 2392 bytes): the payload of the RCCL gather to rank 0"""
+        torch = self.torch
+        cap = self.engine._rec_cap
+        with torch.cuda.stream(self.stream):
+            if self._rec_dev is None:
+                self._rec_dev = torch.empty(cap * _eng.RECORD_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
+            n = self.engine.mcts_drain_records_dev(self._rec_dev.data_ptr(), cap)
+            return self._rec_dev[:n * _eng.RECORD_DTYPE.itemsize].clone()
+
     def stats(self):
         self.stream.synchronize()
         return self.engine.mcts_stats()
@@ -301,56 +325,80 @@ def load_best_model(config):
 
 
 # ---- S3 / S4: make_training_set, play_game --------------------------------------------------------------------------
-def _play_raw(config, network, num_games, seed, device=0, max_slots=1024, streams=None):
-    """plays until num_games games have ended; returns the raw device records (RECORD_DTYPE) of
-    exactly those games, in (episode, slot, ply) order"""
-    slots = min(int(num_games), int(max_slots))
-    sp = SelfPlay(config, network, slots, seed=seed, device=device, streams=streams, auto_reset=num_games > slots)
-    chunks, ended = [], []
-    while len(ended) < num_games:
-        sp.tick(64)
-        r = sp.drain()
-        chunks.append(r)
-        ended += [(int(e), int(sl)) for e, sl in zip(r["episode"][r["kind"] == _eng.REC_GAME_END], r["slot"][r["kind"] == _eng.REC_GAME_END])]
-        st = sp.stats()
-        if st["records_dropped"] or st["overflow"]:
-            raise _eng.EngineError("device record buffer or tree capacity overflowed: %r" % (st,))
-    recs = np.concatenate(chunks)
-    keep = set(sorted(ended)[:num_games])
-    mask = np.array([(int(e), int(sl)) in keep for e, sl in zip(recs["episode"], recs["slot"])], dtype=bool)
-    recs = recs[mask]
-    return recs[np.lexsort((recs["kind"], recs["ply"], recs["slot"], recs["episode"]))]
-
-
-def _play_collect(config, network, num_games, seed, device=0, max_slots=1024, streams=None, as_text=False, packed_only=False):
-    """_play_raw + games_from_records in one pass, with the host's record conversion overlapped with the device: the
-    next 64 ticks are enqueued before the records of the previous 64 are turned into training records."""
-    slots = min(int(num_games), int(max_slots))
-    sp = SelfPlay(config, network, slots, seed=seed, device=device, streams=streams, auto_reset=num_games > slots)
-    col = GameCollector(config, as_text=as_text, packed_only=packed_only)
-    ended = []
-    # ticks between two drains: each drain is a stream sync + copies, ~2 ms against 0.4 ms per tick at 1024 slots; the
-    # device record buffer (default 16 384) must hold what finishes in between: <= slots * chunk / shortest search + games
+def _chunk_ticks(config, slots):
+    """ticks between two drains: each drain is a stream sync + copies, ~2 ms against 0.4 ms per tick at 1024 slots; the
+    device record buffer (default 16 384) must hold what finishes in between: <= slots * chunk / shortest search + games"""
     shortest = config.MAX_ITER
     if config.training and config.use_playout_cap_randomization:
         shortest = max(1, int(config.MAX_ITER / (config.playout_cap_chance * (config.playout_cap_mult - 1) + 1)))
-    chunk = max(16, min(256, (16384 * shortest) // (2 * slots)))
+    if config.use_random_starting_moves:
+        shortest = 1
+    return max(16, min(256, (16384 * shortest) // (2 * slots)))
+
+
+def _play_collect(config, network, num_games, seed, device=0, max_slots=1024, streams=None, as_text=False, packed_only=False,
+                  dist=None):
+    """Plays this process's `num_games` games and returns them as finished games (GameCollector) in (episode, slot) order.
+    Slot s plays a fixed quota of num_games // slots (+1 for the first num_games % slots slots) consecutive games --
+    which games make up a set does not depend on which happen to finish first.
+    The host's record conversion overlaps the device: the next ticks are enqueued before the records of the previous
+    chunk are turned into training records.
+    With an initialised torch.distributed group (`dist`) every rank runs this loop on its own games; after every chunk
+    the ranks' new records are gathered to rank 0 -- over RCCL straight from HBM (SelfPlay.drain_dev, no host bounce on
+    the senders), over gloo from host memory -- while the next chunk is already running, and rank 0 converts them.
+    Rank 0 returns the games of ALL ranks (slot = rank * slots + local slot), the others []."""
+    from . import parallel
+    multi = parallel.active(dist)
+    rank, world = (dist.get_rank(), dist.get_world_size()) if multi else (0, 1)
+    slots = min(int(num_games), int(max_slots))
+    base, extra = divmod(int(num_games), slots)
+    if base + (1 if extra else 0) > 256:
+        raise ValueError("more than 256 games per slot: raise max_slots (episode e of a slot runs on RNG stream + e * 2^24)")
+    sp = SelfPlay(config, network, slots, seed=seed, device=device, streams=streams, auto_reset=num_games > slots,
+                  episodes=(base, extra) if num_games > slots else (0, 0))
+    col = GameCollector(config, as_text=as_text, packed_only=packed_only) if rank == 0 else None
+    nccl = multi and dist.get_backend() == "nccl"
+    cdev = sp.device if nccl else None
+    rec_bytes = _eng.RECORD_DTYPE.itemsize
+    chunk = _chunk_ticks(config, slots)
     sp.tick(chunk)
     while True:
-        r = sp.drain()
-        ended += [(int(e), int(sl)) for e, sl in zip(r["episode"][r["kind"] == _eng.REC_GAME_END], r["slot"][r["kind"] == _eng.REC_GAME_END])]
+        if nccl:
+            mine = sp.drain_dev()                              # stays in HBM
+        else:
+            r = sp.drain()
         st = sp.stats()
-        if st["records_dropped"] or st["overflow"]:
+        bad = int(bool(st["records_dropped"] or st["overflow"]))
+        local_done = st["games"] >= num_games
+        if multi:
+            if not nccl:
+                mine = sp.torch.from_numpy(r.view(np.uint8).reshape(-1))
+            info = parallel.all_gather_ints([mine.numel(), int(local_done), bad], dist, cdev)
+            bad, all_done = int(info[:, 2].any()), bool(info[:, 1].all())
+        else:
+            all_done = local_done
+        if bad:                                                # every rank leaves the loop together
             raise _eng.EngineError("device record buffer or tree capacity overflowed: %r" % (st,))
-        done = len(ended) >= num_games
-        if not done:
-            sp.tick(chunk)                                # the device goes on while the host converts
-        col.add(r[np.lexsort((r["kind"], r["ply"], r["slot"], r["episode"]))])
-        if done:
+        if not local_done:
+            sp.tick(chunk)                                     # the device goes on while the records travel / are converted
+        if multi:
+            parts = parallel.gather_tensor(mine, info[:, 0], dist) if info[:, 0].any() else None
+            if rank == 0 and parts is not None:
+                for rk, part in enumerate(parts):
+                    if part.numel():
+                        rr = np.frombuffer(part.cpu().numpy().tobytes(), dtype=_eng.RECORD_DTYPE).copy()
+                        rr["slot"] += np.uint32(rk * slots)
+                        col.add(rr[np.lexsort((rr["kind"], rr["ply"], rr["slot"], rr["episode"]))])
+        else:
+            col.add(r[np.lexsort((r["kind"], r["ply"], r["slot"], r["episode"]))])
+        if all_done:
             break
-    keep = set(sorted(ended)[:num_games])                 # (episode, slot)
-    games = [g for g in col.finished if (g["key"][1], g["key"][0]) in keep]
+    if rank != 0:
+        return []
+    games = col.finished
     games.sort(key=lambda g: (g["key"][1], g["key"][0]))
+    if len(games) != num_games * world:
+        raise _eng.EngineError("%d games finished, %d expected" % (len(games), num_games * world))
     return games
 
 
@@ -366,34 +414,48 @@ def games_from_records(config, recs, as_text=False):
 def _run_games(config, network, num_games, seed, device=0, max_slots=1024, streams=None, dist=None, as_text=False,
                packed_only=False):
     """Single process: all num_games here.  With an initialised torch.distributed group: rank r plays
-    games [r * G/W, (r+1) * G/W) on its own GPU (disjoint RNG streams, no collective during play) and the
-    packed records are gathered to rank 0, which returns all games; other ranks return []."""
+    games [r * G/W, (r+1) * G/W) on its own GPU (disjoint RNG streams, no collective inside a search tick) and the
+    records are gathered to rank 0 chunk by chunk while the games go on; rank 0 returns all games, other ranks []."""
     from . import parallel
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if parallel.active(dist):
         world, rank = dist.get_world_size(), dist.get_rank()
         if num_games % world:
             raise ValueError("num_games must be a multiple of the world size")
         per = num_games // world
-        recs = _play_raw(config, network, per, seed, device=device, max_slots=max_slots,
-                         streams=parallel.game_streams(rank, min(per, max_slots)))
-        recs = recs.copy()
-        recs["slot"] += np.uint32(rank * max(per, 1))                 # global game id
-        dev = None
-        if dist.get_backend() == "nccl":
-            import torch
-            dev = torch.device("cuda", device)
-        parts = parallel.gather_bytes(np.frombuffer(recs.tobytes(), dtype=np.uint8), dist, dev)
-        if parts is None:
-            return [], None
-        allrecs = np.concatenate([np.frombuffer(p.tobytes(), dtype=_eng.RECORD_DTYPE) for p in parts])
-        return games_from_records(config, allrecs, as_text)[:num_games], None
+        return _play_collect(config, network, per, seed, device=device, max_slots=max_slots,
+                             streams=parallel.game_streams(rank, min(per, max_slots)), as_text=as_text, dist=dist), None
     return _play_collect(config, network, num_games, seed, device=device, max_slots=max_slots, streams=streams,
-                         as_text=as_text, packed_only=packed_only)[:num_games], None
+                         as_text=as_text, packed_only=packed_only), None
 
 
-def play_game(config, interference_network, game_number=None, screen=None, seed=0):
-    """One self-play game -> (data, stats) as ai.py:1570-1699 (screen is ignored: no UI)."""
-    games, _ = _run_games(config, interference_network, 1, seed,
+def _resolve_seed(seed, dist=None, device=0):
+    """seed=None -> fresh randomness (fresh_seed); in a distributed job every rank gets rank 0's draw"""
+    from . import parallel
+    if seed is not None:
+        return int(seed)
+    seed = fresh_seed()
+    if parallel.active(dist):
+        import torch
+        dev = torch.device("cuda", device) if dist.get_backend() == "nccl" else None
+        seed = int(parallel.all_gather_ints([seed], dist, dev)[0, 0])
+    return seed
+
+
+def _log_seed(what, seed, **extra):
+    """seeds that were drawn rather than given are written down, so that a set or a match can be replayed"""
+    try:
+        logs = storage_root() / "logs"
+        logs.mkdir(parents=True, exist_ok=True)
+        with open(logs / "seeds.jsonl", "a") as f:
+            f.write(json.dumps(dict(what=what, seed=int(seed), **extra)) + "\n")
+    except OSError:
+        pass
+
+
+def play_game(config, interference_network, game_number=None, screen=None, seed=None):
+    """One self-play game -> (data, stats) as ai.py:1570-1699 (screen is ignored: no UI).  seed=None: fresh randomness
+    as in the reference; with a seed the game is a function of (seed, game_number)."""
+    games, _ = _run_games(config, interference_network, 1, _resolve_seed(seed),
                           streams=None if game_number is None else np.array([game_number], dtype=np.uint32))
     g = games[0]
     stats = {"model_number": highest_model_number(config), "model_version": config.model_version,
@@ -402,30 +464,37 @@ def play_game(config, interference_network, game_number=None, screen=None, seed=
     return g["data"], stats
 
 
-def make_training_set(config, interference_network, num_games, save_game=False, save_stats=True, screen=None, seed=0,
+def make_training_set(config, interference_network, num_games, save_game=False, save_stats=True, screen=None, seed=None,
                       max_slots=1024, device=0, dist=None, write_json=True):
     """ai.py:1809-1845: plays num_games games, optionally writes {data_dir}/{n}.txt and the averaged
     stats line; returns the records only when save_stats is False (as the reference does).
+    seed=None: fresh randomness per call, as the reference's (two calls never produce the same set); the drawn seed is
+    logged in logs/seeds.jsonl.  An int makes the set reproducible: game g runs on RNG stream g of that seed.
     `dist`: an initialised torch.distributed module -> games are sharded over the ranks (one GPU each),
     records gathered to rank 0 over RCCL; files are written by rank 0 only.
     write_json=False (with save_game and save_stats): only the packed set is written -- the reference's JSON layout is
     ~60 KB of text per record and forming it is what bounds the host; this build's learner reads the packed set."""
+    from . import parallel
+    drawn = seed is None
+    seed = _resolve_seed(seed, dist, device)
     # the records are only written, not returned (the reference's normal call): build them as JSON text directly --
     # the same bytes as json.dumps of the lists at a tenth of the host time (records.record_texts_for_move)
     as_text = bool(save_game and save_stats)
-    packed_only = as_text and not write_json and not (dist is not None and dist.is_initialized() and dist.get_world_size() > 1)
+    packed_only = as_text and not write_json and not parallel.active(dist)
     games, _ = _run_games(config, interference_network, num_games, seed, max_slots=max_slots, device=device, dist=dist,
                           as_text=as_text, packed_only=packed_only)
-    if dist is not None and dist.is_initialized() and dist.get_rank() != 0:
+    if parallel.active(dist) and dist.get_rank() != 0:
         return None
     series_data, series_stats = [], []
     for g in games:
         series_data.extend(g["data"])
         series_stats.append(g["stats"])
+    if drawn and (save_game or save_stats):
+        _log_seed("make_training_set", seed, data_number=highest_data_number(config) + 1, games=int(num_games))
     if save_game:
         os.makedirs(config.data_dir, exist_ok=True)
         next_set = highest_data_number(config) + 1
-        if packed_only:
+        if packed_only or (as_text and not write_json):
             pass
         elif as_text:
             with open("%s/%d.txt" % (config.data_dir, next_set), "wb") as f:
@@ -454,46 +523,97 @@ def make_training_set(config, interference_network, num_games, save_game=False, 
     return series_data
 
 
-def self_play_loop(config, skip_first_set=False, max_sets=None, train_fn=None, gate_fn=None, seed=0, write_json=True):
+def self_play_loop(config, skip_first_set=False, max_sets=None, train_fn=None, gate_fn=None, seed=None, write_json=True,
+                   dist=None, device=0):
     """ai.py:2117-2198: generate a training set with the best model, train a challenger on the recent
     sets, play the gating match, promote the challenger if it meets the threshold -- forever, or
     `max_sets` times.  `train_fn(config, model)` / `gate_fn(challenger, config, best, config, threshold,
-    threshold_type, games) -> (wins, accepted)` replace the built-in learner / gating match."""
+    threshold_type, games) -> (wins, accepted)` replace the built-in learner / gating match.
+
+    seed=None: every set and every match on fresh randomness (the reference's behaviour).  With a base seed the seed of a
+    set / a match is derived from (base, set number on disk, model number on disk), so a resumed loop continues with
+    new games instead of replaying the first sets of the earlier run.
+
+    `dist` (an initialised torch.distributed module, one rank per GPU): the games of a set and of the gating match are
+    sharded over the ranks; rank 0 owns Storage/ -- it writes the sets, trains the challenger and broadcasts its weights
+    (one flat bucket) before the match; the match's win vector is all-reduced, so every rank takes the same decision and
+    ends each round with the same best network."""
+    import inspect
     import torch
     from datetime import datetime
-    from . import gating, learner
-    if highest_model_number(config) == -1:
+    from . import gating, learner, parallel
+    multi = parallel.active(dist)
+    rank = dist.get_rank() if multi else 0
+    dev = torch.device("cuda", device) if torch.cuda.is_available() else torch.device("cpu")
+
+    def barrier():
+        if multi:
+            dist.barrier()
+
+    if rank == 0 and highest_model_number(config) == -1:
         instantiate_network(config, save_network=True)
-    best = load_best_model(config)
+    barrier()
+    if rank == 0:
+        best = load_best_model(config).to(dev)
+    else:
+        best = nets.model_for_config(config.model_config, config.use_tanh).to(dev)
+    parallel.broadcast_state_dict(best, dist)            # every rank starts from rank 0's weights (Storage/ may be rank 0's only)
     training_config = config.copy()
     training_config.training = True
     logs = storage_root() / "logs"
-    logs.mkdir(parents=True, exist_ok=True)
+    if rank == 0:
+        logs.mkdir(parents=True, exist_ok=True)
     it = 0
     while max_sets is None or it < max_sets:
         it += 1
-        challenger = load_best_model(config)
+        challenger = nets.model_for_config(config.model_config, config.use_tanh).to(dev)
+        challenger.load_state_dict(best.state_dict())
         if not skip_first_set:
             for i in range(config.training_loops):
+                tag = parallel.all_gather_ints([highest_data_number(config) + 1, highest_model_number(config)], dist,
+                                               dev if multi and dist.get_backend() == "nccl" else None)[0] if multi else \
+                    (highest_data_number(config) + 1, highest_model_number(config))
+                set_seed = None if seed is None else derive_seed(seed, "set", int(tag[0]), int(tag[1]))
                 make_training_set(training_config, challenger, config.training_games, save_game=True, save_stats=True,
-                                  seed=seed + 1000 * it + i, write_json=write_json)
+                                  seed=set_seed, write_json=write_json, dist=dist, device=device)
         else:
             skip_first_set = False
-        dev = torch.device("cuda", 0) if torch.cuda.is_available() else torch.device("cpu")
-        challenger = challenger.to(dev)
-        (train_fn or learner.load_data_and_train_model)(config, challenger)
-        next_ver = highest_model_number(config) + 1
-        win_loss, win = (gate_fn or gating.battle_networks)(challenger, config, best, config, config.gating_threshold,
-                                                            config.gating_threshold_type, config.battle_games)
-        entry = {"model_version": config.model_version, "challenger_number": next_ver, "challenger_wins": int(win_loss[0]),
-                 "best_wins": int(win_loss[1]), "total_games": config.battle_games,
-                 "win_rate": float(win_loss[0]) / config.battle_games, "accepted": bool(win)}
-        with open(logs / "gating_log.jsonl", "a") as f:
-            f.write(json.dumps(entry) + "\n")
+        next_ver = 0
+        if rank == 0:
+            (train_fn or learner.load_data_and_train_model)(config, challenger)
+            next_ver = highest_model_number(config) + 1
+        parallel.broadcast_state_dict(challenger, dist)    # the trained challenger to every rank for the sharded match
+        if hasattr(challenger, "_folded"):
+            challenger._folded = None
+        gate = gate_fn or gating.battle_networks
+        kw = {}
+        params = inspect.signature(gate).parameters
+        if "seed" in params:
+            tagm = (highest_data_number(config), highest_model_number(config))
+            kw["seed"] = None if seed is None else derive_seed(seed, "gate", int(tagm[0]), int(tagm[1]), it)
+        if "dist" in params and multi:
+            kw["dist"] = dist
+        if "device" in params:
+            kw["device"] = device
+        win_loss, win = gate(challenger, config, best, config, config.gating_threshold, config.gating_threshold_type,
+                             config.battle_games, **kw)
+        if rank == 0:
+            entry = {"model_version": config.model_version, "challenger_number": next_ver, "challenger_wins": int(win_loss[0]),
+                     "best_wins": int(win_loss[1]), "total_games": config.battle_games,
+                     "win_rate": float(win_loss[0]) / config.battle_games, "accepted": bool(win)}
+            with open(logs / "gating_log.jsonl", "a") as f:
+                f.write(json.dumps(entry) + "\n")
         if win:
-            torch.save(challenger.state_dict(), "%s/%d.pt" % (config.model_dir, next_ver))
-            with open(Path(config.model_dir) / "versions.jsonl", "a") as f:           # append_version_record, ai.py:224-234
-                f.write(json.dumps({"timestamp": datetime.utcnow().isoformat() + "Z", "model_number": next_ver,
-                                    "backend": config.model}) + "\n")
+            if rank == 0:
+                torch.save(challenger.state_dict(), "%s/%d.pt" % (config.model_dir, next_ver))
+                with open(Path(config.model_dir) / "versions.jsonl", "a") as f:       # append_version_record, ai.py:224-234
+                    f.write(json.dumps({"timestamp": datetime.utcnow().isoformat() + "Z", "model_number": next_ver,
+                                        "backend": config.model}) + "\n")
             best = challenger
+        barrier()
+    global _last_best
+    _last_best = best                                      # the network this process holds after the loop (tests)
     return it
+
+
+_last_best = None
