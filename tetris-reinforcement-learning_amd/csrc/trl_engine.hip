@@ -304,13 +304,15 @@ int trl_env_reset(trl_engine *h, const uint32_t *stream_ids) {
     uint32_t *d_streams = nullptr;
     if (stream_ids) {
         HIPCHK(hipMalloc(&d_streams, (size_t)n * 4));
-        HIPCHK(hipMemcpyAsync(d_streams, stream_ids, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+        hipError_t ec = hipMemcpyAsync(d_streams, stream_ids, (size_t)n * 4, hipMemcpyHostToDevice, h->stream);
+        if (ec != hipSuccess) { (void)hipFree(d_streams); (void)hipGetLastError(); return fail(TRL_E_HIP, "trl_env_reset: %s", hipGetErrorString(ec)); }
     }
     hipLaunchKernelGGL(k_reset, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, h->stream,
                        h->d_states, d_streams, h->cfg.ruleset, h->cfg.seed, n);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));
-    if (d_streams) HIPCHK(hipFree(d_streams));
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (d_streams) (void)hipFree(d_streams);                   // on the error path too
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(TRL_E_HIP, "trl_env_reset: %s", hipGetErrorString(e)); }
     h->have_reset = true;
     return TRL_OK;
 }

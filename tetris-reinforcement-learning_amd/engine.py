@@ -90,7 +90,9 @@ _lib = None
 
 
 def load_library(path=None):
-    """dlopen libtrl_hip.so (building it first if the sources are newer) and set prototypes."""
+    """dlopen libtrl_hip.so and set prototypes.  Nothing is compiled here: the library is built by
+    tetris_rl_amd.build() / __graft_entry__.build() (hipcc, in-tree) and a missing one is an error -- the GPU box runs
+    the .so that was built with the sources it ships with."""
     global _lib
     if _lib is not None and path is None:
         return _lib

@@ -95,43 +95,62 @@ def search_statistics(child_moves, child_visits):
 
 
 # ---- mirror augmentation (ai.py:1423-1516) ----------------------------------------------------
-def reflect_grid(grid):
-    if isinstance(grid, np.ndarray):
-        return np.fliplr(grid).tolist()
-    return [row[::-1] for row in grid]
-
-
+# Everything is a permutation: of the board columns, of the piece letters (Z<->S, L<->J), and of the 11 583 policy
+# cells (mirror_index(), one precomputed table that the text writer and the packed sets use as well).
 _PIECE_MIRROR = {0: 3, 3: 0, 1: 5, 5: 1}          # Z<->S, L<->J (indices into ZLOSIJT)
+_LETTER_PERM = np.array([_PIECE_MIRROR.get(i, i) for i in range(len(MINOS))])
+_mirror_table = None
+
+
+def mirror_index():
+    """flat policy index -> flat index of its mirror image, -1 where the image leaves the table.  A placement of piece P
+    in rotation r whose box (side b) starts at board column c becomes the mirrored letter in the mirrored rotation
+    (1 <-> 3) at column 10 - c - b; Z / S / I store rotation 3 as rotation 1 one column to the left (const.py:82-118,
+    move_generation.py:698-704), hence the -1 for those."""
+    global _mirror_table
+    if _mirror_table is None:
+        n_plane, n_row, n_col = POLICY_SHAPE
+        table = np.full((n_plane, n_row, n_col), -1, dtype=np.int64)
+        cols = np.arange(n_col)
+        for plane, (piece, rotation, tspin) in enumerate(_PLANE_PIECE):
+            image = MINOS[_PIECE_MIRROR.get(MINOS.index(piece), MINOS.index(piece))]
+            rot = (4 - rotation) % 4                                  # 0, 3, 2, 1
+            shift = 0
+            if image in "ZSI" and rot == 3:
+                rot, shift = 1, -1
+            new_cols = (COLS - (cols - 2) - _BOX[piece]) + 2 + shift
+            ok = (new_cols >= 0) & (new_cols < n_col)
+            base = _plane_of(image, rot, tspin) * n_row
+            for row in range(n_row):
+                table[plane, row, cols[ok]] = (base + row) * n_col + new_cols[ok]
+        _mirror_table = table.reshape(-1)
+    return _mirror_table
+
+
+def reflect_grid(grid):
+    """columns reversed; element types kept (a float32 array gives floats, a list its own elements)"""
+    if isinstance(grid, np.ndarray):
+        return grid[:, ::-1].tolist()
+    return [list(reversed(row)) for row in grid]
 
 
 def reflect_pieces(piece_table):
-    out = np.zeros((2 + PREVIEWS, len(MINOS)), dtype=int)
-    for i, row in enumerate(piece_table):
-        if 1 in row:
-            idx = row.tolist().index(1)
-            out[i][_PIECE_MIRROR.get(idx, idx)] = 1
-    return out
+    """one-hot rows over ZLOSIJT with the letters swapped; integer typed like the reference's (np.zeros(dtype=int))"""
+    return (np.asarray(piece_table)[:, _LETTER_PERM] != 0).astype(int)
 
 
 def reflect_policy(pi):
-    out = np.zeros(POLICY_SHAPE, dtype=int).tolist()
-    letter_mirror = {"Z": "S", "S": "Z", "L": "J", "J": "L"}
-    for plane in range(POLICY_SHAPE[0]):
-        piece, rotation, tspin = _PLANE_PIECE[plane]
-        size = _BOX[piece]
-        new_piece = letter_mirror.get(piece, piece)
-        new_rot = {1: 3, 3: 1}.get(rotation, rotation)
-        adjust = 0
-        if new_piece in ("Z", "S", "I") and new_rot == 3:
-            adjust, new_rot = -1, 1               # rotation 3 is stored as rotation 1 shifted one column
-        new_plane = _plane_of(new_piece, new_rot, tspin)
-        for col in range(POLICY_SHAPE[2]):
-            for row in range(POLICY_SHAPE[1]):
-                v = pi[plane][row][col]
-                if v > 0:
-                    new_col = (10 - (col - 2) - size) + 2 + adjust
-                    out[new_plane][row][new_col] = v
-    return out
+    """every positive cell of the [27][39][11] table moved to its mirror image; integer zeros elsewhere"""
+    n_plane, n_row, n_col = POLICY_SHAPE
+    flat = [v for plane in pi for row in plane for v in row]
+    out = [0] * len(flat)
+    table = mirror_index()
+    for k, v in enumerate(flat):
+        if v > 0:
+            if table[k] < 0:
+                raise IndexError("mirror image of a policy cell leaves the table")
+            out[table[k]] = v
+    return [[out[(pl * n_row + r) * n_col:(pl * n_row + r + 1) * n_col] for r in range(n_row)] for pl in range(n_plane)]
 
 
 def records_for_move(state, child_moves, child_visits, augment=True):
@@ -192,24 +211,7 @@ class _TextTemplates:
         self.pf_txt, self.pf_buf, self.pf_pos = template(np.zeros((2 + PREVIEWS, len(MINOS)), dtype=np.float32))
         self.pi_txt_i, self.pi_buf_i, self.pi_pos_i = template(np.zeros((2 + PREVIEWS, len(MINOS)), dtype=int))
         self.pol_txt, _, self.pol_pos = template(np.zeros(POLICY_SHAPE, dtype=int))
-        # flat policy index -> flat index of its mirror image (reflect_policy), -1 where the image leaves the table
-        n_plane, n_row, n_col = POLICY_SHAPE
-        letter_mirror = {"Z": "S", "S": "Z", "L": "J", "J": "L"}
-        self.mirror = np.full(n_plane * n_row * n_col, -1, dtype=np.int64)
-        for plane in range(n_plane):
-            piece, rotation, tspin = _PLANE_PIECE[plane]
-            size = _BOX[piece]
-            new_piece = letter_mirror.get(piece, piece)
-            new_rot = {1: 3, 3: 1}.get(rotation, rotation)
-            adjust = 0
-            if new_piece in ("Z", "S", "I") and new_rot == 3:
-                adjust, new_rot = -1, 1
-            new_plane = _plane_of(new_piece, new_rot, tspin)
-            for col in range(n_col):
-                new_col = (10 - (col - 2) - size) + 2 + adjust
-                if 0 <= new_col < n_col:
-                    for row in range(n_row):
-                        self.mirror[(plane * n_row + row) * n_col + col] = (new_plane * n_row + row) * n_col + new_col
+        self.mirror = mirror_index()
 
 
 _templates = None
