@@ -354,6 +354,14 @@ int  trl_alphasame_trunk16(const float *dev_boards, int n_boards, const float *d
 /* same, skipping the boards whose dev_need[board] is 0 (their dev_out rows are left untouched) */
 int  trl_alphasame_trunk16_need(const float *dev_boards, int n_boards, const float *dev_packed, int n_blocks,
                                 float *dev_out, const uint8_t *dev_need, void *stream);
+/* The same tower at the f16 matrix rate with fp32 accuracy: every fp32 operand (activations in the kernel, weights on the
+ * host) is split into two halves, a = hi + lo / 2^11, and a product becomes three v_mfma_f32_16x16x32_f16 (hi hi, lo hi,
+ * hi lo) accumulated in fp32 -- 15 matrix instructions of 16 cycles per (16-position tile, conv) instead of 36 of 32.
+ * Logits within 3e-7 of the reference's, as the fp32 MFMA tower (csrc/trl_net.hip k_trunk16s).  dev_packed: conv1
+ * [16][25] fp32; per block s1[16] t1[16] Wa[5][2][64][8 halves] ba[16] Wb[...]; tail as above
+ * (nets.AlphaSame._pack_tower_split).  dev_need may be NULL.                                                         */
+int  trl_alphasame_trunk16_split(const float *dev_boards, int n_boards, const float *dev_packed, int n_blocks,
+                                 float *dev_out, const uint8_t *dev_need, void *stream);
 /* the same tower for filters in {16, 32, 64} (BASELINE config C5 is 20 blocks x 64 filters): F = filters,
  * G = F/16 channel groups and N-tiles.  dev_packed: conv1 [F][25]; per block s1[F] t1[F] Wa ba[F] Wb with a 3x3
  * conv packed as [G channel groups][9 taps][4 j][G N-tiles][64 lanes] = W[16 ntile + lane%16][16 cg + 4 (lane/16) + j][tap]

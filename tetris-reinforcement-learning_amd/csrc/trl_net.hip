@@ -20,6 +20,7 @@
 // 1.6 KB board in, 1.6 KB out and the 188 KB of packed weights (L2-resident, shared by all boards).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "trl_internal.h"
 
 namespace {
@@ -236,6 +237,219 @@ __global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__res
 #pragma unroll
     for (int sidx = 0; sidx < 7; sidx++) {
         int T = wave + 4 * sidx;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float v = fmaxf(fmaf(x[sidx][r], s, t), 0.f) * wk;
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            if (co == 0 && T < NT) out[board * 400 + 16 * T + 4 * g + r] = fmaxf(v + bk, 0.f);
+        }
+    }
+}
+
+
+// ---- the same tower on the f16 matrix rate, at fp32 accuracy: k_trunk16s -------------------------------------------
+// The 1e-5 logit bar forbids a plain f16 / bf16 tower, and the fp32 MFMA runs at 1/16 of the 16-bit matrix rate.  But a
+// fp32 number IS two halves: a = hi + lo / 2^11 with hi = f16(a), lo = f16((a - hi) * 2^11), exact to 2^-22 (|a - hi| <=
+// 2^-11 |a|, rounded again to 11 bits; the scale keeps lo a normal number, so nothing depends on f16 denormals).  With
+// activations and weights both split,
+//     a * w = hi_a hi_w + (lo_a hi_w + hi_a lo_w) / 2^11 + O(2^-22),
+// three v_mfma_f32_16x16x32_f16 (products of halves are exact in fp32, accumulation is fp32) into two accumulators:
+// main (+= hi hi) and corr (+= lo hi + hi lo), result = main + corr / 2^11.  Measured against the reference's logits
+// (tests/golden/net.npz, net_deep.npz): 2.2e-7 max error, the fp32 MFMA tower has 2.4e-7 (a 3-product bf16 split: 3e-6
+// to 1.6e-5, rejected; 6 bf16 products match fp32 but cost twice the MFMAs of this scheme).
+//   * K = 144 = 9 taps x 16 channels in 5 K-steps of 32 (two taps each, the tenth half-step has zero weights): a
+//     lane's A fragment is 8 consecutive channels of one tap = ONE ds_read_b128 from the hi plane and one from the lo
+//     plane ([42 x 12 padded positions][16 channels] halves, 16 KB each -- together the size of the fp32 buffer);
+//   * 15 MFMAs of 16 cycles per (tile, conv) instead of 36 of 32 cycles: 4.8x fewer matrix-pipe cycles;
+//   * B operand: 5 K-steps x {hi, lo} x 4 VGPRs per lane, packed on the host (nets.AlphaSame._pack_tower_split).
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+constexpr int HST = 16;                          // halves per position
+constexpr int HPLANE = PW * PH * HST;            // 8064 halves
+constexpr int WCONV_S = 5 * 2 * 64 * 4;          // packed dwords per 3x3 conv
+constexpr int WBLOCK_S = 16 + 16 + WCONV_S + 16 + WCONV_S;
+constexpr float SPLIT = 2048.f, INV_SPLIT = 1.f / 2048.f;
+
+__device__ __forceinline__ void store_split(_Float16 *hi, _Float16 *lo, int idx, float v) {
+    const _Float16 h = (_Float16)v;
+    hi[idx] = h;
+    lo[idx] = (_Float16)((v - (float)h) * SPLIT);
+}
+
+// B operand of one conv: 10 coalesced 16-byte loads per lane.  Issued BEFORE the activation writes and the barrier that
+// precede the conv, so that their L2 latency is hidden behind them
+__device__ __forceinline__ void load_wsplit(const uint4 *wp, int lane, f16x8 (&wh)[5], f16x8 (&wl)[5]) {
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const uint4 a = wp[(2 * c) * 64 + lane], b = wp[(2 * c + 1) * 64 + lane];
+        wh[c] = __builtin_bit_cast(f16x8, a);
+        wl[c] = __builtin_bit_cast(f16x8, b);
+    }
+}
+
+// am[s] = conv of the wave's tiles (slots 0..5 = tiles wave + 4 s; slot 6 = this wave's K-steps of tile 24).  The
+// correction accumulators live only for the pair of tiles in flight.
+template <bool INIT_BIAS>
+__device__ __forceinline__ void conv3x3s(const _Float16 *hi, const _Float16 *lo, const f16x8 (&wh)[5], const f16x8 (&wl)[5],
+                                         float bias, const int (&base)[7], const int (&koff)[5], int wave, f32x4 (&am)[7]) {
+#pragma unroll
+    for (int s = 0; s < 6; s += 2) {
+        f32x4 m0 = INIT_BIAS ? f32x4{bias, bias, bias, bias} : f32x4{0.f, 0.f, 0.f, 0.f}, m1 = m0;
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const f16x8 h0 = *reinterpret_cast<const f16x8 *>(hi + base[s] + koff[c]);
+            const f16x8 h1 = *reinterpret_cast<const f16x8 *>(hi + base[s + 1] + koff[c]);
+            const f16x8 l0 = *reinterpret_cast<const f16x8 *>(lo + base[s] + koff[c]);
+            const f16x8 l1 = *reinterpret_cast<const f16x8 *>(lo + base[s + 1] + koff[c]);
+            m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, wh[c], m0, 0, 0, 0);
+            m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, wh[c], m1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(l0, wh[c], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(l1, wh[c], c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, wl[c], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, wl[c], c1, 0, 0, 0);
+            if (c & 1) __builtin_amdgcn_sched_barrier(0);        // at most two K-steps of A fragments in flight (registers)
+        }
+        am[s] = m0 + c0 * INV_SPLIT;
+        am[s + 1] = m1 + c1 * INV_SPLIT;
+    }
+    // tile 24 (25 tiles do not divide by 4 waves): its 5 K-steps are shared out 2 / 1 / 1 / 1 and summed through LDS
+    f32x4 m = {0.f, 0.f, 0.f, 0.f}, cc = m;
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        if ((c < 2 ? 0 : c - 1) != wave) continue;
+        const f16x8 h = *reinterpret_cast<const f16x8 *>(hi + base[6] + koff[c]);
+        const f16x8 l = *reinterpret_cast<const f16x8 *>(lo + base[6] + koff[c]);
+        m = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, wh[c], m, 0, 0, 0);
+        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(l, wh[c], cc, 0, 0, 0);
+        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, wl[c], cc, 0, 0, 0);
+    }
+    am[6] = m + cc * INV_SPLIT;
+}
+
+template <int MINB>
+__global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *__restrict__ boards, const float *__restrict__ wts,
+                                                               int n_blocks, float *__restrict__ out,
+                                                               const uint8_t *__restrict__ need) {
+    if (need && !need[blockIdx.x]) return;
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ __attribute__((aligned(16))) float lds[HPLANE + BW * BH + 4 * 256];      // 2 planes of halves = HPLANE floats
+    _Float16 *hiP = reinterpret_cast<_Float16 *>(lds), *loP = hiP + HPLANE;
+    float *brd = lds + HPLANE, *part = lds + HPLANE + BW * BH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, co = lane & 15;
+    const size_t board = blockIdx.x;
+
+    for (int i = tid; i < (HPLANE + BW * BH + 4 * 256) / 4; i += TRUNK_THREADS)
+        reinterpret_cast<f32x4 *>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int i = tid; i < 400; i += TRUNK_THREADS) brd[(i / 10 + 2) * BW + (i % 10) + 2] = boards[board * 400 + i];
+    __syncthreads();
+
+    int base[7];                    // offset (in halves) of the 3x3 window's top-left position of the lane's A row
+#pragma unroll
+    for (int s = 0; s < 7; s++) {
+        const int T = (s < 6) ? wave + 4 * s : NT - 1;
+        const int p = 16 * T + (lane & 15);
+        base[s] = ((p / 10) * PW + (p % 10)) * HST;
+    }
+    // where a lane's C/D values go in the planes: rows 4 g + r of tile T are the four consecutive positions q .. q + 3,
+    // q = 16 T + 4 g; they stay in one board row unless q % 10 == 8 (then r = 2, 3 are in the next row: + 2 padding cells).
+    // One offset per slot and a wrap mask instead of 28 loop-invariant addresses (which cost 28 registers)
+    int wofs[7], wrapmask = 0;
+#pragma unroll
+    for (int s = 0; s < 7; s++) {
+        const int T = (s < 6) ? wave + 4 * s : NT - 1;
+        const int q = 16 * T + 4 * g;
+        wofs[s] = ((q / 10 + 1) * PW + (q % 10) + 1) * HST + co;
+        if (q % 10 == 8) wrapmask |= 1 << s;
+    }
+    int koff[5];                    // K-step c of this lane: tap 2 c + (g >> 1), channels 8 (g & 1) .. + 7
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        int tap = 2 * c + (g >> 1); if (tap > 8) tap = 8;            // the tenth half-step: zero weights, any finite data
+        koff[c] = ((tap / 3) * PW + (tap % 3)) * HST + 8 * (g & 1);
+    }
+
+    // 5x5 stem, one input channel: im2col GEMM on the fp32 matrix instruction as in k_trunk16 (7 MFMAs per tile, once)
+    f32x4 x[7];
+    {
+        float wB[7];
+        int toff[7];
+#pragma unroll
+        for (int st = 0; st < 7; st++) {
+            const int t = 4 * st + g, tc = t < 25 ? t : 24;
+            wB[st] = t < 25 ? wts[co * 25 + tc] : 0.f;
+            toff[st] = (tc / 5) * BW + (tc % 5);
+        }
+#pragma unroll
+        for (int s = 0; s < 7; s++) {
+            int T = wave + 4 * s; if (T >= NT) T = NT - 1;
+            const int p = 16 * T + (lane & 15), pb = (p / 10) * BW + (p % 10);
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 7; st++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(brd[pb + toff[st]], wB[st], c, 0, 0, 0);
+            x[s] = c;
+        }
+    }
+
+    const float *wb = wts + 400;
+    f32x4 am[7];
+    f16x8 wh[5], wl[5];
+    for (int b = 0; b < n_blocks; b++, wb += WBLOCK_S) {
+        const float s1 = wb[co], t1 = wb[16 + co], bias_a = wb[32 + WCONV_S + co];
+        load_wsplit(reinterpret_cast<const uint4 *>(wb + 32), lane, wh, wl);
+#pragma unroll
+        for (int s = 0; s < 7; s++) {                               // H1 = relu(bn1(x)), split, own positions
+            if (s < 6 || wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    store_split(hiP, loP, wofs[s] + r * HST + ((r >= 2 && ((wrapmask >> s) & 1)) ? 2 * HST : 0),
+                                fmaxf(fmaf(x[s][r], s1, t1), 0.f));
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
+        conv3x3s<true>(hiP, loP, wh, wl, bias_a, base, koff, wave, am);
+        __builtin_amdgcn_s_setprio(3);
+        *reinterpret_cast<f32x4 *>(part + wave * 256 + lane * 4) = am[6];
+        load_wsplit(reinterpret_cast<const uint4 *>(wb + 32 + WCONV_S + 16), lane, wh, wl);      // conv B's weights
+        __syncthreads();                              // every wave has read its halo: the planes can be overwritten
+        if (wave == 0) {
+            f32x4 t = *reinterpret_cast<const f32x4 *>(part + lane * 4);
+            t += *reinterpret_cast<const f32x4 *>(part + 256 + lane * 4);
+            t += *reinterpret_cast<const f32x4 *>(part + 512 + lane * 4);
+            t += *reinterpret_cast<const f32x4 *>(part + 768 + lane * 4);
+            am[6] = t + f32x4{bias_a, bias_a, bias_a, bias_a};
+        }
+#pragma unroll
+        for (int s = 0; s < 7; s++) {
+            if (s < 6 || wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    store_split(hiP, loP, wofs[s] + r * HST + ((r >= 2 && ((wrapmask >> s) & 1)) ? 2 * HST : 0), fmaxf(am[s][r], 0.f));
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
+        conv3x3s<false>(hiP, loP, wh, wl, 0.f, base, koff, wave, am);
+        __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int s = 0; s < 6; s++) x[s] += am[s];
+        *reinterpret_cast<f32x4 *>(part + wave * 256 + lane * 4) = am[6];
+        __syncthreads();
+        if (wave == 0) {
+            f32x4 t = *reinterpret_cast<const f32x4 *>(part + lane * 4);
+            t += *reinterpret_cast<const f32x4 *>(part + 256 + lane * 4);
+            t += *reinterpret_cast<const f32x4 *>(part + 512 + lane * 4);
+            t += *reinterpret_cast<const f32x4 *>(part + 768 + lane * 4);
+            x[6] += t;
+        }
+    }
+    // tail: relu(bn(x)) -> 1x1 conv over the 16 channels (= 16 lanes) -> folded bn -> relu   (fp32, as k_trunk16)
+    const float s = wb[co], t = wb[16 + co], wk = wb[32 + co], bk = wb[48];
+#pragma unroll
+    for (int sidx = 0; sidx < 7; sidx++) {
+        const int T = wave + 4 * sidx;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             float v = fmaxf(fmaf(x[sidx][r], s, t), 0.f) * wk;
@@ -529,6 +743,23 @@ int trl_alphasame_trunk16_need(const float *dev_boards, int n_boards, const floa
         return fail(TRL_E_INVALID, "trl_alphasame_trunk16: %s", "bad argument");
     hipLaunchKernelGGL(k_trunk16, dim3(n_boards), dim3(TRUNK_THREADS), 0, (hipStream_t)stream, dev_boards, dev_packed,
                        n_blocks, dev_out, dev_need);
+    HIPCHK(hipGetLastError());
+    return TRL_OK;
+}
+
+// The 16-filter tower on the f16 matrix rate with every fp32 operand split into two halves (k_trunk16s above): same
+// contract as trl_alphasame_trunk16_need; dev_packed in the layout of nets.AlphaSame._pack_tower_split().
+int trl_alphasame_trunk16_split(const float *dev_boards, int n_boards, const float *dev_packed, int n_blocks,
+                                float *dev_out, const uint8_t *dev_need, void *stream) {
+    if (!dev_boards || !dev_packed || !dev_out || n_boards <= 0 || n_blocks < 0)
+        return fail(TRL_E_INVALID, "trl_alphasame_trunk16_split: %s", "bad argument");
+    static const int occ = getenv("TRL_SPLIT_OCC") ? atoi(getenv("TRL_SPLIT_OCC")) : 2;       // probe knob (3: 168 VGPRs, spills)
+    if (occ == 2)
+        hipLaunchKernelGGL(k_trunk16s<2>, dim3(n_boards), dim3(TRUNK_THREADS), 0, (hipStream_t)stream, dev_boards, dev_packed,
+                           n_blocks, dev_out, dev_need);
+    else
+        hipLaunchKernelGGL(k_trunk16s<3>, dim3(n_boards), dim3(TRUNK_THREADS), 0, (hipStream_t)stream, dev_boards, dev_packed,
+                           n_blocks, dev_out, dev_need);
     HIPCHK(hipGetLastError());
     return TRL_OK;
 }

@@ -13,6 +13,8 @@ inference module with its own forward:
   * output is what evaluate() returns (ai.py:1222-1319): sigmoid value [n] and softmaxed policy
     [n, 11583].
 """
+import os
+
 import torch
 from torch import nn
 import torch.nn.functional as F
@@ -66,6 +68,31 @@ def _pack_conv3x3(w, f):
     return out.reshape(-1)
 
 
+SPLIT_SCALE = 2048.0        # csrc/trl_net.hip k_trunk16s: a = hi + lo / 2^11
+
+
+def _pack_conv3x3_split(w):
+    """w [16 out, 16 in, 3, 3] -> the B operands of v_mfma_f32_16x16x32_f16 for the split tower (k_trunk16s):
+    [K-step c = 0..4][hi | lo][lane][8 halves]; lane (n = lane % 16, g = lane // 16) holds W[n][8 (g & 1) + j][tap] for
+    tap = 2 c + (g >> 1) (zero for the tenth half-step); hi = f16(w), lo = f16((w - hi) * 2^11).  Returned as float32
+    words (bit patterns), 2560 per conv."""
+    dev = w.device
+    lane = torch.arange(64, device=dev)
+    n, g = lane & 15, lane >> 4
+    w9 = w.reshape(16, 16, 9).to(torch.float32)
+    out = torch.zeros((5, 2, 64, 8), dtype=torch.float16, device=dev)
+    for c in range(5):
+        tap = 2 * c + (g >> 1)
+        ok = tap <= 8
+        tapc = torch.clamp(tap, max=8)
+        for j in range(8):
+            v = torch.where(ok, w9[n, 8 * (g & 1) + j, tapc], torch.zeros(64, device=dev))
+            hi = v.to(torch.float16)
+            out[c, 0, :, j] = hi
+            out[c, 1, :, j] = ((v - hi.to(torch.float32)) * SPLIT_SCALE).to(torch.float16)
+    return out.reshape(-1).view(torch.float32)
+
+
 class AlphaSame(nn.Module):
     def __init__(self, model_config=None, use_tanh=False):
         super().__init__()
@@ -88,6 +115,8 @@ class AlphaSame(nn.Module):
                                          "3": nn.Linear(mc.value_head_neurons, 1)})
         self._folded = None
         self.use_hip_trunk = True       # fused HIP tower when the net is on the GPU and filters is 16, 32 or 64
+        # 16 filters: "split" = k_trunk16s (f16 matrix rate, operands split in two halves, fp32 accuracy), "fp32" = k_trunk16
+        self.tower_mode = os.environ.get("TRL_TOWER", "split")
         self.eval()
 
     # -- folding ------------------------------------------------------------------------------
@@ -111,6 +140,8 @@ class AlphaSame(nn.Module):
         fd["v0"] = ((self.value_head["0"].weight * sv.view(-1, 1)).contiguous(), (self.value_head["0"].bias * sv + tv).contiguous())
         fd["packed_tower"] = self._pack_tower(fd) if (self.model_config.filters in self.HIP_TOWER_FILTERS and self.model_config.kernels == 1
                                               and self.conv1.weight.is_cuda) else None
+        # the 16-filter tower on the f16 matrix rate with split operands (k_trunk16s): fp32 accuracy, see csrc/trl_net.hip
+        fd["packed_split"] = self._pack_tower_split(fd) if (fd["packed_tower"] is not None and self.model_config.filters == 16) else None
         self._folded = fd
         return self
 
@@ -133,6 +164,18 @@ class AlphaSame(nn.Module):
         # padding: the wide kernels prefetch the weights one K-step past the end of a conv
         parts += [s.reshape(-1), t.reshape(-1), wk.reshape(-1), bk.reshape(-1), torch.zeros(15 + (0 if f == 16 else 4096), device=dev)]
         return torch.cat([p.to(torch.float32) for p in parts]).contiguous()
+
+    def _pack_tower_split(self, fd):
+        """packed weights of k_trunk16s: stem [16][25] fp32; per block s1[16] t1[16] convA (2560 words) ba[16] convB (2560);
+        tail s[16] t[16] wk[16] bk + padding"""
+        dev = self.conv1.weight.device
+        parts = [self.conv1.weight.reshape(16, 25).reshape(-1)]
+        for s1, t1, wa, ba, wb in fd["blocks"]:
+            parts += [s1.reshape(-1), t1.reshape(-1), _pack_conv3x3_split(wa), ba.reshape(-1), _pack_conv3x3_split(wb)]
+        s, t = fd["tail"]
+        wk, bk = fd["k1"]
+        parts += [s.reshape(-1), t.reshape(-1), wk.reshape(-1), bk.reshape(-1), torch.zeros(15, device=dev)]
+        return torch.cat([p.to(torch.float32) if p.dtype != torch.float32 else p for p in parts]).contiguous()
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
@@ -174,9 +217,15 @@ class AlphaSame(nn.Module):
             out = torch.empty((m, ROWS * COLS), dtype=torch.float32, device=boards.device)
         else:
             out = torch.zeros((m, ROWS * COLS), dtype=torch.float32, device=boards.device)
-        rc = L.trl_alphasame_trunk(x.data_ptr(), m, packed.data_ptr(), self.model_config.filters, len(self.res_blocks),
-                                   out.data_ptr(), None if need is None else need.data_ptr(),
-                                   torch.cuda.current_stream(boards.device).cuda_stream)
+        split = self._folded.get("packed_split") if (self._folded and self.tower_mode == "split") else None
+        if split is not None and packed is self._folded["packed_tower"]:
+            rc = L.trl_alphasame_trunk16_split(x.data_ptr(), m, split.data_ptr(), len(self.res_blocks), out.data_ptr(),
+                                               None if need is None else need.data_ptr(),
+                                               torch.cuda.current_stream(boards.device).cuda_stream)
+        else:
+            rc = L.trl_alphasame_trunk(x.data_ptr(), m, packed.data_ptr(), self.model_config.filters, len(self.res_blocks),
+                                       out.data_ptr(), None if need is None else need.data_ptr(),
+                                       torch.cuda.current_stream(boards.device).cuda_stream)
         if rc != 0:
             raise _eng.EngineError("trl_alphasame_trunk failed: %s" % L.trl_last_error().decode())
         return out
