@@ -362,6 +362,11 @@ int  trl_alphasame_trunk16_need(const float *dev_boards, int n_boards, const flo
  * (nets.AlphaSame._pack_tower_split).  dev_need may be NULL.                                                         */
 int  trl_alphasame_trunk16_split(const float *dev_boards, int n_boards, const float *dev_packed, int n_blocks,
                                  float *dev_out, const uint8_t *dev_need, void *stream);
+/* The 32- and 64-filter towers in the same way (csrc/trl_net.hip k_trunk_wide_s): resnet = 0: AlphaSame, contract of
+ * trl_alphasame_trunk (kout ignored); resnet != 0: the BaseResNet family, contract of trl_resnet_trunk.  dev_packed as for
+ * those, with every 3x3 conv as [K-step = kg * 9 + tap][hi | lo][N-tile][64 lanes][8 halves] (nets._pack_conv3x3_split_wide). */
+int  trl_trunk_wide_split(const float *dev_boards, int n_boards, const float *dev_packed, int filters, int n_blocks, int resnet,
+                          int kout, float *dev_out, const uint8_t *dev_need, void *stream);
 /* the same tower for filters in {16, 32, 64} (BASELINE config C5 is 20 blocks x 64 filters): F = filters,
  * G = F/16 channel groups and N-tiles.  dev_packed: conv1 [F][25]; per block s1[F] t1[F] Wa ba[F] Wb with a 3x3
  * conv packed as [G channel groups][9 taps][4 j][G N-tiles][64 lanes] = W[16 ntile + lane%16][16 cg + 4 (lane/16) + j][tap]

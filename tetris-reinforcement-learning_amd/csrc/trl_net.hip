@@ -725,6 +725,309 @@ __global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float
     }
 }
 
+// ---- wide towers on the f16 matrix rate with split operands (see k_trunk16s): k_trunk_wide_s<32|64> -----------------
+// Same scheme as k_trunk16s -- a = hi + lo / 2^11, three v_mfma_f32_16x16x32_f16 per product, fp32 accumulation -- on the
+// data flow of k_trunk_wide (weights streamed from L2 one K-step ahead and reused by all M-tiles of the wave; residual
+// stream and accumulators in registers), one wave per N-tile.  K = 9 taps x FF channels in 9 FF/32 K-steps
+// of 32 channels of one tap (no padding: 576 = 18 x 32): 54 matrix instructions of 16 cycles per (tile, N-tile, conv) at
+// FF = 64 instead of 144 of 32 cycles.
+//   * activations: hi and lo planes of halves, FF/8 "oct-planes" [42 x 12 padded positions][8 channels] each (8 KB): the
+//     A fragment of a lane (position m, channels 8 g .. 8 g + 7 of the K-step's 32) is ONE ds_read_b128 from plane 4 kg + g,
+//     consecutive lanes read consecutive 16-byte cells; FF = 64: 2 x 64 KB -- the size of the fp32 planes;
+//   * packed weights (nets._pack_conv3x3_split_wide): [K-step = kg * 9 + tap][hi | lo][N-tile][lane][8 halves], lane
+//     (n, g) holds W[16 ntile + n][32 kg + 8 g + j][tap]; 147 KB per conv at FF = 64, as many bytes as the fp32 layout.
+// MS = 1: one wave per N-tile carrying all 25 M-tiles -- one wave per SIMD, the whole 512-entry register file (residual
+//         stream, main and correction accumulators = 300 registers), every weight crosses the L2 once per conv and board;
+// MS = 2: two waves per N-tile (even / odd M-tiles, as k_trunk_wide) -- two waves per SIMD with 256 registers each.
+template <int FF, int MS = 1> struct WideS {
+    static constexpr int NN = FF / 16, KG = FF / 32, WAVES = MS * NN, MSPLIT = MS, TS = (NT + MSPLIT - 1) / MSPLIT;
+    static constexpr int THREADS = 64 * WAVES, OCT = FF / 8;
+    static constexpr int PLANEH = 4096;                    // halves per oct-plane: 504 positions x 8, padded to 8 KB
+    static constexpr int HALF_FLOATS = OCT * PLANEH / 2;   // floats of the hi (or lo) planes
+    static constexpr int LDS_FLOATS = 2 * HALF_FLOATS + BW * BH + 200;
+    static constexpr int KSTEPS = 9 * KG;
+    static constexpr int WSTEP = 2 * NN * 64 * 4;          // packed dwords per K-step (hi and lo, all N-tiles)
+    static constexpr int CONVW = KSTEPS * WSTEP;
+};
+
+// tiles of group G (of 6: 4, 4, 4, 4, 4, 5 of the 25 M-tiles)
+template <int G> struct WGrp { static constexpr int S0 = 4 * G, S1 = (G == 5) ? NT : 4 * G + 4, N = S1 - S0; };
+
+template <int G>
+__device__ __forceinline__ void wides_load(const _Float16 *ph, const _Float16 *pl, const int (&base)[NT], int off,
+                                           f16x8 (&ah)[5], f16x8 (&al)[5]) {
+#pragma unroll
+    for (int s = WGrp<G>::S0; s < WGrp<G>::S1; s++) {
+        ah[s - WGrp<G>::S0] = *reinterpret_cast<const f16x8 *>(ph + base[s] + off);
+        al[s - WGrp<G>::S0] = *reinterpret_cast<const f16x8 *>(pl + base[s] + off);
+    }
+}
+template <int G>
+__device__ __forceinline__ void wides_mfma(const f16x8 (&ah)[5], const f16x8 (&al)[5], f16x8 bh, f16x8 bl, f32x4 (&am)[NT], f32x4 (&ac)[NT]) {
+#pragma unroll
+    for (int s = WGrp<G>::S0; s < WGrp<G>::S1; s++) am[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s - WGrp<G>::S0], bh, am[s], 0, 0, 0);
+#pragma unroll
+    for (int s = WGrp<G>::S0; s < WGrp<G>::S1; s++) ac[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s - WGrp<G>::S0], bh, ac[s], 0, 0, 0);
+#pragma unroll
+    for (int s = WGrp<G>::S0; s < WGrp<G>::S1; s++) ac[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s - WGrp<G>::S0], bl, ac[s], 0, 0, 0);
+}
+
+// am[s] (+)= conv of all 25 tiles; wh / wl = the first K-step's B operand (already in flight).
+// One wave per SIMD: nothing hides a stall but the wave's own instruction stream, so the A fragments are software-
+// pipelined one group ahead (two register buffers; six groups per K-step, so the buffer of a group is fixed) and the
+// weights one K-step ahead; each group issues 12-15 matrix instructions (192-240 cycles) over the next group's 8-10 reads.
+template <int FF>
+__device__ __forceinline__ void conv_wide_s(const _Float16 *hiL, const _Float16 *loL, const uint4 *wq, f16x8 wh, f16x8 wl,
+                                            const int (&base)[NT], f32x4 (&am)[NT], f32x4 (&ac)[NT]) {
+    using W = WideS<FF>;
+    constexpr int STEPQ = W::WSTEP / 4;                    // uint4 per K-step
+    f16x8 ah0[5], al0[5], ah1[5], al1[5];
+    wides_load<0>(hiL, loL, base, 0, ah0, al0);
+    for (int kg = 0; kg < W::KG; kg++) {
+        const _Float16 *ph = hiL + kg * 4 * W::PLANEH, *pl = loL + kg * 4 * W::PLANEH;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; tap++) {
+            const f16x8 bh = wh, bl = wl;
+            wq += STEPQ;                                   // next K-step (the last prefetch of a conv reads what follows it: unused)
+            wh = __builtin_bit_cast(f16x8, wq[0]);
+            wl = __builtin_bit_cast(f16x8, wq[W::NN * 64]);
+            const int ty = tap / 3, off = (ty * PW + (tap - 3 * ty)) * 8;
+            const int tn = tap == 8 ? 0 : tap + 1, tny = tn / 3, offn = (tny * PW + (tn - 3 * tny)) * 8;
+            const _Float16 *phn = (tap == 8 && kg + 1 < W::KG) ? ph + 4 * W::PLANEH : ph;      // (the last prefetch of a conv is unused)
+            const _Float16 *pln = (tap == 8 && kg + 1 < W::KG) ? pl + 4 * W::PLANEH : pl;
+            wides_load<1>(ph, pl, base, off, ah1, al1);
+            __builtin_amdgcn_sched_barrier(0);
+            wides_mfma<0>(ah0, al0, bh, bl, am, ac);
+            __builtin_amdgcn_sched_barrier(0);
+            wides_load<2>(ph, pl, base, off, ah0, al0);
+            __builtin_amdgcn_sched_barrier(0);
+            wides_mfma<1>(ah1, al1, bh, bl, am, ac);
+            __builtin_amdgcn_sched_barrier(0);
+            wides_load<3>(ph, pl, base, off, ah1, al1);
+            __builtin_amdgcn_sched_barrier(0);
+            wides_mfma<2>(ah0, al0, bh, bl, am, ac);
+            __builtin_amdgcn_sched_barrier(0);
+            wides_load<4>(ph, pl, base, off, ah0, al0);
+            __builtin_amdgcn_sched_barrier(0);
+            wides_mfma<3>(ah1, al1, bh, bl, am, ac);
+            __builtin_amdgcn_sched_barrier(0);
+            wides_load<5>(ph, pl, base, off, ah1, al1);
+            __builtin_amdgcn_sched_barrier(0);
+            wides_mfma<4>(ah0, al0, bh, bl, am, ac);
+            __builtin_amdgcn_sched_barrier(0);
+            wides_load<0>(phn, pln, base, offn, ah0, al0);
+            __builtin_amdgcn_sched_barrier(0);
+            wides_mfma<5>(ah1, al1, bh, bl, am, ac);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// the same for the 12 or 13 tiles of a wave at MS = 2: two waves per SIMD cover each other's LDS latency, the A fragments
+// of a group of 4-5 tiles are read right before their 12-15 matrix instructions
+template <int FF, int NTL>
+__device__ __forceinline__ void conv_wide_s2(const _Float16 *hiL, const _Float16 *loL, const uint4 *wq, f16x8 wh, f16x8 wl,
+                                             const int (&base)[13], f32x4 (&am)[13], f32x4 (&ac)[13]) {
+    using W = WideS<FF, 2>;
+    constexpr int STEPQ = W::WSTEP / 4;
+    for (int kg = 0; kg < W::KG; kg++) {
+        const _Float16 *ph = hiL + kg * 4 * W::PLANEH, *pl = loL + kg * 4 * W::PLANEH;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; tap++) {
+            const f16x8 bh = wh, bl = wl;
+            wq += STEPQ;
+            wh = __builtin_bit_cast(f16x8, wq[0]);
+            wl = __builtin_bit_cast(f16x8, wq[W::NN * 64]);
+            const int ty = tap / 3, off = (ty * PW + (tap - 3 * ty)) * 8;
+#pragma unroll
+            for (int s0 = 0; s0 < NTL; s0 += 4) {
+                const int s1 = (s0 + 8 > NTL) ? NTL : s0 + 4;          // 4, 4, 4 or 4, 4, 5 tiles
+                f16x8 ah[5], al[5];
+#pragma unroll
+                for (int s = s0; s < s1; s++) {
+                    ah[s - s0] = *reinterpret_cast<const f16x8 *>(ph + base[s] + off);
+                    al[s - s0] = *reinterpret_cast<const f16x8 *>(pl + base[s] + off);
+                }
+#pragma unroll
+                for (int s = s0; s < s1; s++) am[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s - s0], bh, am[s], 0, 0, 0);
+#pragma unroll
+                for (int s = s0; s < s1; s++) ac[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s - s0], bh, ac[s], 0, 0, 0);
+#pragma unroll
+                for (int s = s0; s < s1; s++) ac[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s - s0], bl, ac[s], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s1 == NTL) break;
+            }
+        }
+    }
+}
+
+template <int FF, bool POST, int MS>
+__global__ __launch_bounds__((WideS<FF, MS>::THREADS), MS) void k_trunk_wide_s(const float *__restrict__ boards,
+                                                                        const float *__restrict__ wts, int n_blocks,
+                                                                        float *__restrict__ out,
+                                                                        const uint8_t *__restrict__ need, int kout) {
+    using W = WideS<FF, MS>;
+    constexpr int TS = W::TS, NN = W::NN, MSPLIT = W::MSPLIT, THREADS = W::THREADS;
+    constexpr int STEM = POST ? 9 : 25;
+    if (need && !need[blockIdx.x]) return;
+    __shared__ __attribute__((aligned(16))) float lds[W::LDS_FLOATS];
+    _Float16 *hiP = reinterpret_cast<_Float16 *>(lds), *loP = hiP + W::OCT * W::PLANEH;
+    float *brd = lds + 2 * W::HALF_FLOATS;
+    uint2 *otab = reinterpret_cast<uint2 *>(brd + BW * BH);   // otab[p / 4]: cell offsets (in halves) of positions p .. p + 3
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, co = lane & 15;
+    const int ntile = wave % NN, mq = wave / NN;
+    const int ch = ntile * 16 + co;
+    const size_t board = blockIdx.x;
+
+    for (int i = tid; i < W::LDS_FLOATS / 4; i += THREADS) reinterpret_cast<f32x4 *>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int i = tid; i < 400; i += THREADS) brd[(i / 10 + 2) * BW + (i % 10) + 2] = boards[board * 400 + i];
+    for (int i = tid; i < 100; i += THREADS) {
+        unsigned o[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { int p = 4 * i + r; o[r] = ((p / 10 + 1) * PW + (p % 10) + 1) * 8; }
+        otab[i] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+    }
+    __syncthreads();
+
+    int base[TS];                   // cell offset (in halves) of the 3x3 window's top-left position of the lane's A row
+#pragma unroll
+    for (int s = 0; s < TS; s++) {
+        int T = mq + MSPLIT * s; if (T >= NT) T = NT - 1;
+        int p = 16 * T + (lane & 15);
+        base[s] = ((p / 10) * PW + (p % 10)) * 8;
+    }
+
+    f32x4 x[TS];
+    {
+        float w1[STEM];
+#pragma unroll
+        for (int i = 0; i < STEM; i++) w1[i] = wts[ch * STEM + i];
+        const float b0 = POST ? wts[FF * STEM + ch] : 0.f;
+#pragma unroll
+        for (int s = 0; s < TS; s++) {
+            int T = mq + MSPLIT * s; if (T >= NT) T = NT - 1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int p = 16 * T + 4 * g + r, py = p / 10, px = p % 10;
+                float a = b0;
+                if (POST) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) a = fmaf(w1[k], brd[(py + 1 + k / 3) * BW + px + 1 + (k % 3)], a);
+                    a = fmaxf(a, 0.f);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 25; k++) a = fmaf(w1[k], brd[(py + k / 5) * BW + px + (k % 5)], a);
+                }
+                x[s][r] = a;
+            }
+        }
+    }
+
+    // this lane's output channel: oct-plane ch / 8, sub-channel ch % 8; its A rows: plane 4 kg + g
+    _Float16 *ownh = hiP + (2 * ntile + (co >> 3)) * W::PLANEH + (co & 7), *ownl = ownh + W::OCT * W::PLANEH;
+    const _Float16 *hiL = hiP + g * W::PLANEH, *loL = loP + g * W::PLANEH;
+    const float *wb = wts + FF * STEM + (POST ? FF : 0);
+    f32x4 am[TS], ac[TS];
+    for (int layer = 0; layer < 2 * n_blocks; layer++) {
+        const bool first = !(layer & 1);
+        float sc = 1.f, sh = 0.f, bias = 0.f;
+        const float *wq;
+        if (POST) {                                    // block: b1[F] W1 b2[F] W2
+            bias = first ? wb[ch] : wb[FF + W::CONVW + ch];
+            wq = wb + (first ? FF : 2 * FF + W::CONVW);
+        } else {                                       // block: s1[F] t1[F] Wa ba[F] Wb
+            if (first) { sc = wb[ch]; sh = wb[FF + ch]; bias = wb[2 * FF + W::CONVW + ch]; }
+            wq = wb + (first ? 2 * FF : 3 * FF + W::CONVW);
+        }
+        const uint4 *wq4 = reinterpret_cast<const uint4 *>(wq) + ntile * 64 + lane;
+        const f16x8 wh = __builtin_bit_cast(f16x8, wq4[0]), wl = __builtin_bit_cast(f16x8, wq4[NN * 64]);
+        // conv input -> planes (own positions), split: the block input (pre-activation: through bn1 + relu) for the first
+        // conv, relu(previous conv) for the second
+#pragma unroll
+        for (int s = 0; s < TS; s++) {
+            int T = mq + MSPLIT * s;
+            if (T < NT) {
+                const uint2 o = otab[4 * T + g];
+                const unsigned off[4] = {o.x & 0xffffu, o.x >> 16, o.y & 0xffffu, o.y >> 16};
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float v = fmaxf(first ? (POST ? x[s][r] : fmaf(x[s][r], sc, sh)) : am[s][r], 0.f);
+                    const _Float16 h = (_Float16)v;
+                    ownh[off[r]] = h;
+                    ownl[off[r]] = (_Float16)((v - (float)h) * SPLIT);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < TS; s++) { am[s] = f32x4{bias, bias, bias, bias}; ac[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if constexpr (MS == 1) conv_wide_s<FF>(hiL, loL, wq4, wh, wl, base, am, ac);
+        else {
+            if (mq == 0) conv_wide_s2<FF, 13>(hiL, loL, wq4, wh, wl, base, am, ac);
+            else conv_wide_s2<FF, 12>(hiL, loL, wq4, wh, wl, base, am, ac);
+        }
+#pragma unroll
+        for (int s = 0; s < TS; s++) am[s] += ac[s] * INV_SPLIT;
+        if (!first) {
+#pragma unroll
+            for (int s = 0; s < TS; s++) {
+                x[s] += am[s];
+                if (POST) { x[s][0] = fmaxf(x[s][0], 0.f); x[s][1] = fmaxf(x[s][1], 0.f); x[s][2] = fmaxf(x[s][2], 0.f); x[s][3] = fmaxf(x[s][3], 0.f); }
+            }
+            wb += POST ? 2 * FF + 2 * W::CONVW : 3 * FF + 2 * W::CONVW;
+        }
+        __syncthreads();                              // every wave has read its inputs: the planes can be overwritten
+    }
+
+    float *part = lds;                                 // [kout][NN][400] partial sums (the planes are dead now)
+    if (POST) {
+        for (int k = 0; k < kout; k++) {               // tail: kout 1x1 projections of the feature map, raw
+            const float wk = wb[k * FF + ch];
+#pragma unroll
+            for (int sidx = 0; sidx < TS; sidx++) {
+                int T = mq + MSPLIT * sidx;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float v = x[sidx][r] * wk;
+                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                    if (co == 0 && T < NT) part[(k * NN + ntile) * 400 + 16 * T + 4 * g + r] = v;
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 400 * kout; i += THREADS) {
+            const int k = i / 400, pos = i % 400;
+            float v = 0.f;
+#pragma unroll
+            for (int n = 0; n < NN; n++) v += part[(k * NN + n) * 400 + pos];
+            out[(board * kout + k) * 400 + pos] = v;
+        }
+    } else {
+        // tail: relu(bn(x)) -> 1x1 conv over the FF channels (16 lanes x NN waves) -> folded bn -> relu
+        const float s = wb[ch], t = wb[FF + ch], wk = wb[2 * FF + ch], bk = wb[3 * FF];
+#pragma unroll
+        for (int sidx = 0; sidx < TS; sidx++) {
+            int T = mq + MSPLIT * sidx;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float v = fmaxf(fmaf(x[sidx][r], s, t), 0.f) * wk;
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                if (co == 0 && T < NT) part[ntile * 400 + 16 * T + 4 * g + r] = v;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < 400; i += THREADS) {
+            float v = bk;
+#pragma unroll
+            for (int n = 0; n < NN; n++) v += part[n * 400 + i];
+            out[board * 400 + i] = fmaxf(v, 0.f);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -779,6 +1082,31 @@ int trl_alphasame_trunk(const float *dev_boards, int n_boards, const float *dev_
                            dev_packed, n_blocks, dev_out, dev_need, 1);
     else
         return fail(TRL_E_INVALID, "trl_alphasame_trunk: %s", "the fused tower exists for 16, 32 and 64 filters");
+    HIPCHK(hipGetLastError());
+    return TRL_OK;
+}
+
+// The wide towers at the f16 matrix rate with split operands (k_trunk_wide_s): same contracts as trl_alphasame_trunk /
+// trl_resnet_trunk for filters 32 and 64, with the 3x3 convolutions packed by nets._pack_conv3x3_split_wide.
+// resnet != 0: the BaseResNet family (kout raw projections), else AlphaSame (kout ignored).
+int trl_trunk_wide_split(const float *dev_boards, int n_boards, const float *dev_packed, int filters, int n_blocks, int resnet,
+                         int kout, float *dev_out, const uint8_t *dev_need, void *stream) {
+    if (!dev_boards || !dev_packed || !dev_out || n_boards <= 0 || n_blocks < 0 || (resnet && (kout < 1 || kout > 8)))
+        return fail(TRL_E_INVALID, "trl_trunk_wide_split: %s", "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    static const int ms = getenv("TRL_WIDE_MS") ? atoi(getenv("TRL_WIDE_MS")) : 2;      // probe knob: waves per N-tile
+    if (filters != 32 && filters != 64)
+        return fail(TRL_E_INVALID, "trl_trunk_wide_split: %s", "the split wide tower exists for 32 and 64 filters");
+#define TRL_LAUNCH_WS(FF_, POST_, MS_) hipLaunchKernelGGL((k_trunk_wide_s<FF_, POST_, MS_>), dim3(n_boards), dim3(WideS<FF_, MS_>::THREADS), \
+                                                          0, st, dev_boards, dev_packed, n_blocks, dev_out, dev_need, resnet ? kout : 1)
+    if (ms == 1) {
+        if (filters == 64) { if (resnet) TRL_LAUNCH_WS(64, true, 1); else TRL_LAUNCH_WS(64, false, 1); }
+        else { if (resnet) TRL_LAUNCH_WS(32, true, 1); else TRL_LAUNCH_WS(32, false, 1); }
+    } else {
+        if (filters == 64) { if (resnet) TRL_LAUNCH_WS(64, true, 2); else TRL_LAUNCH_WS(64, false, 2); }
+        else { if (resnet) TRL_LAUNCH_WS(32, true, 2); else TRL_LAUNCH_WS(32, false, 2); }
+    }
+#undef TRL_LAUNCH_WS
     HIPCHK(hipGetLastError());
     return TRL_OK;
 }

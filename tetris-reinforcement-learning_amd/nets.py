@@ -93,6 +93,26 @@ def _pack_conv3x3_split(w):
     return out.reshape(-1).view(torch.float32)
 
 
+def _pack_conv3x3_split_wide(w, f):
+    """w [f out, f in, 3, 3] (f = 32 or 64) -> the B operands of k_trunk_wide_s:
+    [K-step = kg * 9 + tap][hi | lo][N-tile][lane][8 halves]; lane (n = lane % 16, g = lane // 16) of N-tile nt holds
+    W[16 nt + n][32 kg + 8 g + j][tap]; hi = f16(w), lo = f16((w - hi) * 2^11).  float32 words (bit patterns)."""
+    dev = w.device
+    nn_, kgs = f // 16, f // 32
+    lane = torch.arange(64, device=dev)
+    n, g = lane & 15, lane >> 4
+    w9 = w.reshape(f, f, 9).to(torch.float32)
+    v = torch.empty((kgs, 9, nn_, 64, 8), dtype=torch.float32, device=dev)
+    for kg in range(kgs):
+        for nt in range(nn_):
+            for j in range(8):
+                v[kg, :, nt, :, j] = w9[16 * nt + n, 32 * kg + 8 * g + j, :].transpose(0, 1)
+    hi = v.to(torch.float16)
+    lo = ((v - hi.to(torch.float32)) * SPLIT_SCALE).to(torch.float16)
+    out = torch.stack([hi, lo], dim=2)                    # [kg][tap][2][nt][lane][8]
+    return out.reshape(-1).view(torch.float32)
+
+
 class AlphaSame(nn.Module):
     def __init__(self, model_config=None, use_tanh=False):
         super().__init__()
@@ -115,7 +135,8 @@ class AlphaSame(nn.Module):
                                          "3": nn.Linear(mc.value_head_neurons, 1)})
         self._folded = None
         self.use_hip_trunk = True       # fused HIP tower when the net is on the GPU and filters is 16, 32 or 64
-        # 16 filters: "split" = k_trunk16s (f16 matrix rate, operands split in two halves, fp32 accuracy), "fp32" = k_trunk16
+        # "split" = k_trunk16s / k_trunk_wide_s (f16 matrix rate, operands split in two halves, fp32 accuracy),
+        # "fp32" = k_trunk16 / k_trunk_wide (fp32 matrix instructions)
         self.tower_mode = os.environ.get("TRL_TOWER", "split")
         self.eval()
 
@@ -141,7 +162,7 @@ class AlphaSame(nn.Module):
         fd["packed_tower"] = self._pack_tower(fd) if (self.model_config.filters in self.HIP_TOWER_FILTERS and self.model_config.kernels == 1
                                               and self.conv1.weight.is_cuda) else None
         # the 16-filter tower on the f16 matrix rate with split operands (k_trunk16s): fp32 accuracy, see csrc/trl_net.hip
-        fd["packed_split"] = self._pack_tower_split(fd) if (fd["packed_tower"] is not None and self.model_config.filters == 16) else None
+        fd["packed_split"] = self._pack_tower_split(fd) if fd["packed_tower"] is not None else None
         self._folded = fd
         return self
 
@@ -169,12 +190,15 @@ class AlphaSame(nn.Module):
         """packed weights of k_trunk16s: stem [16][25] fp32; per block s1[16] t1[16] convA (2560 words) ba[16] convB (2560);
         tail s[16] t[16] wk[16] bk + padding"""
         dev = self.conv1.weight.device
-        parts = [self.conv1.weight.reshape(16, 25).reshape(-1)]
+        f = self.model_config.filters
+        pack = _pack_conv3x3_split if f == 16 else (lambda w: _pack_conv3x3_split_wide(w, f))
+        parts = [self.conv1.weight.reshape(f, 25).reshape(-1)]
         for s1, t1, wa, ba, wb in fd["blocks"]:
-            parts += [s1.reshape(-1), t1.reshape(-1), _pack_conv3x3_split(wa), ba.reshape(-1), _pack_conv3x3_split(wb)]
+            parts += [s1.reshape(-1), t1.reshape(-1), pack(wa), ba.reshape(-1), pack(wb)]
         s, t = fd["tail"]
         wk, bk = fd["k1"]
-        parts += [s.reshape(-1), t.reshape(-1), wk.reshape(-1), bk.reshape(-1), torch.zeros(15, device=dev)]
+        # padding: the wide kernel prefetches the weights one K-step past the end of a conv
+        parts += [s.reshape(-1), t.reshape(-1), wk.reshape(-1), bk.reshape(-1), torch.zeros(15 + (0 if f == 16 else 4096), device=dev)]
         return torch.cat([p.to(torch.float32) if p.dtype != torch.float32 else p for p in parts]).contiguous()
 
     def load_state_dict(self, *a, **k):
@@ -218,10 +242,14 @@ class AlphaSame(nn.Module):
         else:
             out = torch.zeros((m, ROWS * COLS), dtype=torch.float32, device=boards.device)
         split = self._folded.get("packed_split") if (self._folded and self.tower_mode == "split") else None
-        if split is not None and packed is self._folded["packed_tower"]:
+        if split is not None and packed is self._folded["packed_tower"] and self.model_config.filters == 16:
             rc = L.trl_alphasame_trunk16_split(x.data_ptr(), m, split.data_ptr(), len(self.res_blocks), out.data_ptr(),
                                                None if need is None else need.data_ptr(),
                                                torch.cuda.current_stream(boards.device).cuda_stream)
+        elif split is not None and packed is self._folded["packed_tower"]:
+            rc = L.trl_trunk_wide_split(x.data_ptr(), m, split.data_ptr(), self.model_config.filters, len(self.res_blocks), 0, 1,
+                                        out.data_ptr(), None if need is None else need.data_ptr(),
+                                        torch.cuda.current_stream(boards.device).cuda_stream)
         else:
             rc = L.trl_alphasame_trunk(x.data_ptr(), m, packed.data_ptr(), self.model_config.filters, len(self.res_blocks),
                                        out.data_ptr(), None if need is None else need.data_ptr(),
@@ -387,6 +415,7 @@ class BaseResNet(nn.Module):
                                          "3": nn.Linear(mc.value_hidden, 1)})
         self._folded = None
         self.use_hip_trunk = True       # fused HIP tower when the net is on the GPU and filters is 32 or 64
+        self.tower_mode = os.environ.get("TRL_TOWER", "split")     # "split": k_trunk_wide_s, "fp32": k_trunk_wide
         self.eval()
 
     @torch.no_grad()
@@ -409,6 +438,11 @@ class BaseResNet(nn.Module):
             # tail: the own_kernels rows of own_collapse, then the row of opp_collapse (kout = own_kernels + 1)
             parts += [fd["own"][0].reshape(-1), fd["opp"][0].reshape(-1), torch.zeros(4096, device=fd["own"][0].device)]
             fd["packed_tower"] = torch.cat([p.reshape(-1).to(torch.float32) for p in parts]).contiguous()
+            parts = [fd["stem"][0].reshape(-1), fd["stem"][1]]
+            for (w1, b1), (w2, b2) in fd["blocks"]:
+                parts += [b1, _pack_conv3x3_split_wide(w1, f), b2, _pack_conv3x3_split_wide(w2, f)]
+            parts += [fd["own"][0].reshape(-1), fd["opp"][0].reshape(-1), torch.zeros(4096, device=fd["own"][0].device)]
+            fd["packed_split"] = torch.cat([p.reshape(-1).to(torch.float32) for p in parts]).contiguous()
         self._folded = fd
         return self
 
@@ -422,9 +456,15 @@ class BaseResNet(nn.Module):
         x = boards.reshape(m, ROWS * COLS).contiguous()
         alloc = torch.empty if need is None else torch.zeros
         out = alloc((m, kout, ROWS * COLS), dtype=torch.float32, device=boards.device)
-        rc = L.trl_resnet_trunk(x.data_ptr(), m, packed.data_ptr(), self.model_config.filters, len(self.trunk), kout,
-                                out.data_ptr(), None if need is None else need.data_ptr(),
-                                torch.cuda.current_stream(boards.device).cuda_stream)
+        split = self._folded.get("packed_split") if (self._folded and self.tower_mode == "split") else None
+        if split is not None and packed is self._folded["packed_tower"]:
+            rc = L.trl_trunk_wide_split(x.data_ptr(), m, split.data_ptr(), self.model_config.filters, len(self.trunk), 1, kout,
+                                        out.data_ptr(), None if need is None else need.data_ptr(),
+                                        torch.cuda.current_stream(boards.device).cuda_stream)
+        else:
+            rc = L.trl_resnet_trunk(x.data_ptr(), m, packed.data_ptr(), self.model_config.filters, len(self.trunk), kout,
+                                    out.data_ptr(), None if need is None else need.data_ptr(),
+                                    torch.cuda.current_stream(boards.device).cuda_stream)
         if rc != 0:
             raise _eng.EngineError("trl_resnet_trunk failed: %s" % L.trl_last_error().decode())
         return out
