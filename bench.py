@@ -175,6 +175,7 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
 
 
 WIDE_FLOP_PER_BOARD = 2 * 400 * (25 * 64 + 40 * 576 * 64 + 64)      # C5 tower: conv5x5 + 40 conv3x3 (64 ch) + conv1x1 = 1.18 GFLOP
+WIDE_SPLIT_FLOP_PER_BOARD = 2 * 400 * (25 * 64 + 40 * 576 * 64 * 3 + 64)   # k_trunk_wide_s: three f16 products per multiply
 
 
 def bench_c5(args, rank, local_rank, world, dist, dev, barrier):
@@ -222,7 +223,12 @@ def bench_c5(args, rank, local_rank, world, dist, dev, barrier):
     trunk_ms = e0.elapsed_time(e1) / reps
     elapsed, moves_total = parallel.reduce_job(elapsed, st1["moves"] - st0["moves"], dist, dev)
     _, sims_total = parallel.reduce_job(elapsed, st1["simulations"] - st0["simulations"], dist, dev)
-    tflops = WIDE_FLOP_PER_BOARD * 2 * n / (trunk_ms * 1e-3) / 1e12
+    split = getattr(sp.net, "tower_mode", "fp32") == "split"
+    algo_tflops = WIDE_FLOP_PER_BOARD * 2 * n / (trunk_ms * 1e-3) / 1e12
+    if split:
+        tflops, peak, kname = WIDE_SPLIT_FLOP_PER_BOARD * 2 * n / (trunk_ms * 1e-3) / 1e12, MFMA_F16_PEAK_TFLOPS, "k_trunk_wide_s<64>"
+    else:
+        tflops, peak, kname = algo_tflops, MFMA_F32_PEAK_TFLOPS, "k_trunk_wide<64>"
     return {
         "metric": "MCTS simulations/sec at MAX_ITER=800 (GPU search + AlphaSame(20,64) fp32, forced playouts + pruning)",
         "value": round(sims_total / elapsed, 1), "unit": "simulations/s",
@@ -232,9 +238,14 @@ def bench_c5(args, rank, local_rank, world, dist, dev, barrier):
                                "2000/400), forced playouts + policy-target pruning, AlphaSame blocks=20 filters=64 random init"
                                % n, "games_per_gpu": n, "ticks_timed": args.c5_ticks, "moves_completed": moves_total,
                    "simulations_timed": sims_total},
-        "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(tflops / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None, "kernel": "k_trunk_wide<64>",
-                     "kernel_ms": round(trunk_ms, 4), "flop_per_board": WIDE_FLOP_PER_BOARD, "boards_per_launch": 2 * n},
+        "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(tflops / peak, 4), "traffic": None, "kernel": kname,
+                     "kernel_ms": round(trunk_ms, 4), "flop_per_board": WIDE_SPLIT_FLOP_PER_BOARD if split else WIDE_FLOP_PER_BOARD,
+                     "boards_per_launch": 2 * n, "algorithmic_tflops": round(algo_tflops, 2),
+                     "algorithmic_flop_per_board": WIDE_FLOP_PER_BOARD,
+                     "note": ("f16 matrix instructions on split fp32 operands (3 products per multiply): the algorithmic rate is %.2f x "
+                              "the fp32 matrix peak of %.1f TFLOP/s" % (algo_tflops / MFMA_F32_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS))
+                             if split else "fp32 matrix instructions"},
     }
 
 
