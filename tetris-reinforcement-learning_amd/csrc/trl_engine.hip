@@ -230,15 +230,17 @@ int trl_engine_create(const trl_config *cfg, trl_engine **out) {
         HIPCHK(hipMalloc(&h->d_counts, n * sizeof(uint16_t)));
         HIPCHK(hipMalloc(&h->d_moves, n * TRL_MAX_LEGAL * sizeof(uint16_t)));
         HIPCHK(hipMalloc(&h->d_in_moves, n * sizeof(uint16_t)));
-        HIPCHK(hipMalloc(&h->d_steps, 2 * sizeof(unsigned long long)));       // [0] steps
-        HIPCHK(hipMalloc(&h->d_prog, (n + 63) / 64 * 64 * sizeof(unsigned int)));              // plies played in this launch, per slot (rollout pacing)
+        // one block, zeroed by one memset per rollout launch: [0] env-steps of the launch (+ 8 bytes of padding), then the
+        // plies played in the launch per slot (rollout pacing)
+        HIPCHK(hipMalloc(&h->d_steps, 16 + (n + 63) / 64 * 64 * sizeof(unsigned int)));
+        h->d_prog = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(h->d_steps) + 16);
         HIPCHK(hipEventCreate(&h->ev0));
         HIPCHK(hipEventCreate(&h->ev1));
         return TRL_OK;
     };
     int rc = alloc();
     if (rc != TRL_OK) {                            // release what was allocated before the failure
-        hipFree(h->d_states); hipFree(h->d_counts); hipFree(h->d_moves); hipFree(h->d_in_moves); hipFree(h->d_steps); hipFree(h->d_prog);
+        hipFree(h->d_states); hipFree(h->d_counts); hipFree(h->d_moves); hipFree(h->d_in_moves); hipFree(h->d_steps);
         if (h->ev0) hipEventDestroy(h->ev0);
         if (h->ev1) hipEventDestroy(h->ev1);
         if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -256,7 +258,7 @@ void trl_engine_destroy(trl_engine *h) {
     trl_mcts_free_internal(h);
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
     if (h->graph) hipGraphDestroy(h->graph);
-    hipFree(h->d_states); hipFree(h->d_counts); hipFree(h->d_moves); hipFree(h->d_in_moves); hipFree(h->d_steps); hipFree(h->d_prog);
+    hipFree(h->d_states); hipFree(h->d_counts); hipFree(h->d_moves); hipFree(h->d_in_moves); hipFree(h->d_steps);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
@@ -401,13 +403,13 @@ int trl_env_rollout_random(trl_engine *h, int n_plies, int max_plies, uint64_t *
     if (!h || n_plies < 0 || max_plies <= 0) return fail(TRL_E_INVALID, "%s", "bad argument");
     if (!h->have_reset) return fail(TRL_E_STATE, "%s", "trl_env_rollout_random before trl_env_reset / trl_env_set_state");
     HIPCHK(hipSetDevice(h->cfg.device));
-    HIPCHK(hipMemsetAsync(h->d_steps, 0, 2 * sizeof(unsigned long long), h->stream));
+    const size_t prog_bytes = ((size_t)h->cfg.n_games + 63) / 64 * 64 * sizeof(unsigned int);
     int pacing = h->cfg.n_games <= 16 * h->n_cu;                            // 16 workgroups of this kernel fit a CU
     int r3 = 4, r2 = 16, r1 = 40;                                           // ranks (of 64) that get priority 3 / 2 / 1
     if (const char *e = getenv("TRL_PACE")) pacing = atoi(e) != 0;          // probe knobs (scripts/rollout_tail_probe.py)
     if (const char *e = getenv("TRL_PACE_R")) sscanf(e, "%d,%d,%d", &r3, &r2, &r1);
     const int rankt = pacing ? ((r3 & 255) | ((r2 & 255) << 8) | ((r1 & 255) << 16)) : 0;
-    if (rankt) HIPCHK(hipMemsetAsync(h->d_prog, 0, ((size_t)h->cfg.n_games + 63) / 64 * 64 * sizeof(unsigned int), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_steps, 0, 16 + (rankt ? prog_bytes : 0), h->stream));
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(k_rollout, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->d_states, h->cfg.seed,
                        n_plies, max_plies, h->d_steps, h->d_prog, rankt);
