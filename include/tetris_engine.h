@@ -286,6 +286,11 @@ int  trl_mcts_select(trl_engine *h, float *dev_grids, float *dev_vec);
  *                         fills in the reused ones from the parent's cache entry and stores both outputs in the
  *                         leaf's entry, so that afterwards dev_z is complete for the heads. */
 int  trl_mcts_select_need(trl_engine *h, float *dev_grids, float *dev_vec, uint8_t *dev_need);
+/* on != 0: from now on trl_mcts_select_need leaves the leaf's legal-move search (get_move_matrix, 78 % of the select
+ * kernel) to a second kernel that the library runs on a stream of its own BESIDE the caller's tower -- the tower needs the
+ * leaf's boards only -- and the next trl_mcts_expand* call waits for it.  Inside trl_graph_begin / _end the fork and the
+ * join become edges of the captured graph.  Results are the same bit for bit. */
+int  trl_mcts_fork_legal(trl_engine *h, int on);
 /* floats of tower output per board the cache holds (default 400 = AlphaSame's process_grid output; the BaseResNet
  * family caches its (own_kernels + 1) x 400 raw projections).  Call before the first tick: the cache is reallocated. */
 int  trl_mcts_zcache_dim(trl_engine *h, int floats_per_board);

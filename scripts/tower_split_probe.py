@@ -1,5 +1,5 @@
 """k_trunk16s (split-f16 tower) against k_trunk16 (fp32 MFMA tower): accuracy against the reference's logits and time.
-usage: python scripts/tower_split_probe.py   (TRL_SPLIT_OCC=2|3 picks the occupancy variant of the split kernel)"""
+usage: python scripts/tower_split_probe.py   (TRL_SPLIT_ILV=0|1 forces the grouped / interleaved fragment-read form of the split kernel)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -11,7 +11,7 @@ d = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file_
 net = load_net(d, "b10f16", 10, 16, device="cuda")
 grids, vec = packed_features(d["states"])
 g, v = torch.from_numpy(grids).cuda(), torch.from_numpy(vec).cuda()
-print("TRL_SPLIT_OCC =", os.environ.get("TRL_SPLIT_OCC", "3 (default)"))
+print("TRL_SPLIT_ILV =", os.environ.get("TRL_SPLIT_ILV", "by board count (default)"))
 for mode in ("fp32", "split"):
     net.tower_mode = mode
     val, logits = net.heads(g, v)

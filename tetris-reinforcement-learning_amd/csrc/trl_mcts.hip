@@ -137,7 +137,10 @@ __device__ unsigned long long g_mprof[16];     // [0..4] k_select phases, [8..12
 #endif
 
 // ---- tick part A --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *real, float *grids, float *vec, uint8_t *need) {
+// do_legal = 0: the legal-move search of the leaf is left to k_leaf_legal, which runs beside the net's tower on a second
+// stream (the tower needs the leaf's boards only); leaf_nlegal is filled in there.
+__global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *real, float *grids, float *vec, uint8_t *need,
+                                                  int do_legal) {
     __shared__ SelectShared sh;
     const int tid = threadIdx.x, slot = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t nb = (size_t)slot * M.max_nodes;
@@ -273,8 +276,10 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
     else if (no_move(g)) kind = 1;
     else {
         kind = 0;
-        nlegal = block_movegen(sh.b, tid);
-        for (int i = tid; i < nlegal; i += BLOCK) M.leaf_moves[(size_t)slot * TRL_MAX_LEGAL + i] = merged_move(sh.b, i);
+        if (do_legal) {
+            nlegal = block_movegen(sh.b, tid);
+            for (int i = tid; i < nlegal; i += BLOCK) M.leaf_moves[(size_t)slot * TRL_MAX_LEGAL + i] = merged_move(sh.b, i);
+        } else if (tid == 0) sh.b.overflow = 0;
     }
 
     // game_to_X (ai.py:1364-1413): side to move first
@@ -320,11 +325,28 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
             int w = g.p[0].game_over ? 1 : (g.p[1].game_over ? 0 : -1);      // Game.winner, game.py:217-225
             c.terminal_value = (w == g.turn) ? 1.0 : (w == 1 - g.turn) ? (cfg.use_tanh ? -1.0 : 0.0) : (cfg.use_tanh ? 0.0 : 0.5);
         }
-        if (kind == 0 && sh.b.overflow) { c.overflow = 1; atomicAdd(&M.counters[5], 1ull); }     // a legal-move cap was hit
+        if (kind == 0 && do_legal && sh.b.overflow) { c.overflow = 1; atomicAdd(&M.counters[5], 1ull); }     // a legal-move cap was hit
         M.ctl[slot] = c;
         atomicAdd(&M.counters[0], 1ull);
     }
     MPROF_T(ms5); MPROF_ADD(4, ms4, ms5);
+}
+
+// the legal-move search of every slot's current leaf (get_move_matrix + get_move_list, ai.py:414-417), split off k_select:
+// 64 VGPRs and 10 KB of LDS per workgroup, so it runs in the registers the tower's two workgroups per CU leave free
+__global__ __launch_bounds__(BLOCK, 8) void k_leaf_legal(DevMcts M) {
+    __shared__ BlockShared sh;
+    const int tid = threadIdx.x, slot = blockIdx.x;
+    const int phase = M.ctl[slot].phase, kind = M.ctl[slot].leaf_kind, sidx = M.ctl[slot].leaf_state;
+    if (phase != 1 || kind != 0) return;
+    load_state(sh, M.pool + (size_t)slot * M.cap_states + sidx, tid);
+    __syncthreads();
+    const int nlegal = block_movegen(sh, tid);
+    for (int i = tid; i < nlegal; i += BLOCK) M.leaf_moves[(size_t)slot * TRL_MAX_LEGAL + i] = merged_move(sh, i);
+    if (tid == 0) {
+        M.ctl[slot].leaf_nlegal = nlegal;
+        if (sh.overflow) { M.ctl[slot].overflow = 1; atomicAdd(&M.counters[5], 1ull); }
+    }
 }
 
 // ---- tick part B --------------------------------------------------------------------------------------
@@ -838,6 +860,10 @@ struct trl_mcts {
     trl_game_state *d_leaf_tmp;
     int32_t *d_info_tmp;
     void *d_root_tmp;
+    int fork_legal;                 // trl_mcts_fork_legal: the leaf's legal-move search runs on side_stream beside the tower
+    bool fork_pending;              // k_leaf_legal is in flight: the next expand joins it
+    hipStream_t side_stream;
+    hipEvent_t ev_fork, ev_join;
 };
 
 static void free_dev(DevMcts &d) {
@@ -851,6 +877,9 @@ void trl_mcts_free_internal(trl_engine *h) {
     if (!h || !h->mcts) return;
     free_dev(h->mcts->d);
     hipFree(h->mcts->d_leaf_tmp); hipFree(h->mcts->d_info_tmp); hipFree(h->mcts->d_root_tmp);
+    if (h->mcts->side_stream) { hipStreamSynchronize(h->mcts->side_stream); hipStreamDestroy(h->mcts->side_stream); }
+    if (h->mcts->ev_fork) hipEventDestroy(h->mcts->ev_fork);
+    if (h->mcts->ev_join) hipEventDestroy(h->mcts->ev_join);
     delete h->mcts;
     h->mcts = nullptr;
 }
@@ -928,8 +957,43 @@ int trl_mcts_select(trl_engine *h, float *dev_grids, float *dev_vec) {
 int trl_mcts_select_need(trl_engine *h, float *dev_grids, float *dev_vec, uint8_t *dev_need) {
     if (!h || !h->mcts || !dev_grids || !dev_vec) return fail(TRL_E_INVALID, "trl_mcts_select: %s", "null argument / no search attached");
     HIPCHK(hipSetDevice(h->cfg.device));
-    hipLaunchKernelGGL(k_select, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_grids, dev_vec, dev_need);
+    trl_mcts *m = h->mcts;
+    const int fork = m->fork_legal && dev_need;         // only the tower-need flow has something to overlap with
+    hipLaunchKernelGGL(k_select, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, m->d, h->d_states, dev_grids, dev_vec, dev_need,
+                       fork ? 0 : 1);
     HIPCHK(hipGetLastError());
+    if (fork) {
+        // fork: side_stream waits for k_select, runs k_leaf_legal; the next expand call joins (mcts_join).  Under stream
+        // capture (trl_graph_begin) the two event waits become the graph's fork and join edges.
+        HIPCHK(hipEventRecord(m->ev_fork, h->stream));
+        HIPCHK(hipStreamWaitEvent(m->side_stream, m->ev_fork, 0));
+        hipLaunchKernelGGL(k_leaf_legal, dim3(h->cfg.n_games), dim3(BLOCK), 0, m->side_stream, m->d);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(m->ev_join, m->side_stream));
+        m->fork_pending = true;
+    }
+    return TRL_OK;
+}
+
+static int mcts_join(trl_engine *h) {
+    trl_mcts *m = h->mcts;
+    if (m->fork_pending) {
+        HIPCHK(hipStreamWaitEvent(h->stream, m->ev_join, 0));
+        m->fork_pending = false;
+    }
+    return TRL_OK;
+}
+
+int trl_mcts_fork_legal(trl_engine *h, int on) {
+    if (!h || !h->mcts) return fail(TRL_E_INVALID, "trl_mcts_fork_legal: %s", "no search attached");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    trl_mcts *m = h->mcts;
+    if (on && !m->side_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&m->side_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    }
+    m->fork_legal = on ? 1 : 0;
     return TRL_OK;
 }
 
@@ -958,6 +1022,7 @@ int trl_mcts_zcache(trl_engine *h, float *dev_z) {
 int trl_mcts_expand(trl_engine *h, const float *dev_values, const float *dev_policy) {
     if (!h || !h->mcts || !dev_values || !dev_policy) return fail(TRL_E_INVALID, "trl_mcts_expand: %s", "null argument / no search attached");
     HIPCHK(hipSetDevice(h->cfg.device));
+    { int rcj = mcts_join(h); if (rcj != TRL_OK) return rcj; }
     hipLaunchKernelGGL(k_expand<0>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_values,
                        dev_policy, (const float *)nullptr, (const float *)nullptr, 0, HeadsDev{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0});
     HIPCHK(hipGetLastError());
@@ -970,6 +1035,7 @@ int trl_mcts_expand_head(trl_engine *h, const float *dev_values, const float *de
     if (!h || !h->mcts || !dev_values || !dev_feats || !dev_head_weight || !dev_head_bias || feat_dim <= 0 || feat_dim > HEAD_MAX_FEATS)
         return fail(TRL_E_INVALID, "trl_mcts_expand_head: %s", "bad argument / no search attached");
     HIPCHK(hipSetDevice(h->cfg.device));
+    { int rcj = mcts_join(h); if (rcj != TRL_OK) return rcj; }
     hipLaunchKernelGGL(k_expand<1>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_values,
                        dev_feats, dev_head_weight, dev_head_bias, feat_dim, HeadsDev{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0});
     HIPCHK(hipGetLastError());
@@ -985,6 +1051,7 @@ int trl_mcts_expand_alphasame_masked(trl_engine *h, const float *dev_z, const fl
     HIPCHK(hipSetDevice(h->cfg.device));
     if (h->mcts->d.zdim != 400) return fail(TRL_E_STATE, "%s", "trl_mcts_expand_alphasame needs the 400-float tower cache (trl_mcts_zcache_dim)");
     HeadsDev H{w->oside_w, w->oside_b, w->value0_w, w->value0_b, w->value3_w, w->value3_b, w->use_tanh, dev_slot_mask, want};
+    { int rcj = mcts_join(h); if (rcj != TRL_OK) return rcj; }
     hipLaunchKernelGGL(k_expand<2>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_vec,
                        dev_z, w->policy_w, w->policy_b, 521, H);
     HIPCHK(hipGetLastError());
@@ -1042,6 +1109,7 @@ int trl_mcts_leaf_states(trl_engine *h, trl_game_state *host_out, int32_t *host_
     if (!h || !h->mcts || !host_out || !host_info) return fail(TRL_E_INVALID, "trl_mcts_leaf_states: %s", "bad argument");
     HIPCHK(hipSetDevice(h->cfg.device));
     int n = h->cfg.n_games;
+    { int rcj = mcts_join(h); if (rcj != TRL_OK) return rcj; }
     hipLaunchKernelGGL(k_leaf_gather, dim3(n), dim3(128), 0, h->stream, h->mcts->d, h->mcts->d_leaf_tmp, h->mcts->d_info_tmp);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(host_out, h->mcts->d_leaf_tmp, (size_t)n * sizeof(trl_game_state), hipMemcpyDeviceToHost, h->stream));

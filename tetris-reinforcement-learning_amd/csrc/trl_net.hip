@@ -259,20 +259,32 @@ __global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__res
 // to 1.6e-5, rejected; 6 bf16 products match fp32 but cost twice the MFMAs of this scheme).
 //   * K = 144 = 9 taps x 16 channels in 5 K-steps of 32 (two taps each, the tenth half-step has zero weights): a
 //     lane's A fragment is 8 consecutive channels of one tap = ONE ds_read_b128 from the hi plane and one from the lo
-//     plane ([42 x 12 padded positions][16 channels] halves, 16 KB each -- together the size of the fp32 buffer);
+//     plane (rows of [12 hi positions | 12 lo positions][16 channels] halves at a pitch of 26 positions, 34 KB);
 //   * 15 MFMAs of 16 cycles per (tile, conv) instead of 36 of 32 cycles: 4.8x fewer matrix-pipe cycles;
 //   * B operand: 5 K-steps x {hi, lo} x 4 VGPRs per lane, packed on the host (nets.AlphaSame._pack_tower_split).
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr int HST = 16;                          // halves per position
-constexpr int HPLANE = PW * PH * HST;            // 8064 halves
+// Row pitch of the split planes, in positions: a row holds its 12 hi positions (10 + the zero border) at 0..11 and its 12
+// lo positions at 13..24.  26 = 10 + 16: stepping from one board row to the next moves a tile's positions by a multiple of
+// 8 positions = 256 bytes = all 64 banks, so the 16 positions of a tile -- which span two or three board rows -- fall on
+// distinct banks like 16 consecutive positions do (ds_read_b128: 4 cycles).  Two separate planes of pitch 12 moved the
+// positions after a row end by 64 bytes and every fragment read took two passes (8 cycles; scripts/lds_bank_sim.py) --
+// with 4 KB of fragments per wave and K-step that, not the matrix pipe, set the pace of the convs.
+constexpr int SPW = 26, LO_OFS = 13 * HST;
+constexpr int HPLANE = SPW * PH * HST / 2;       // both halves of every position, in floats (8736)
 constexpr int WCONV_S = 5 * 2 * 64 * 4;          // packed dwords per 3x3 conv
 constexpr int WBLOCK_S = 16 + 16 + WCONV_S + 16 + WCONV_S;
 constexpr float SPLIT = 2048.f, INV_SPLIT = 1.f / 2048.f;
 
-__device__ __forceinline__ void store_split(_Float16 *hi, _Float16 *lo, int idx, float v) {
-    const _Float16 h = (_Float16)v;
-    hi[idx] = h;
-    lo[idx] = (_Float16)((v - (float)h) * SPLIT);
+using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
+
+// four values (the lane's four channels of one position) -> hi and lo halves, one 8-byte store each
+__device__ __forceinline__ void store_split4(_Float16 *hi, _Float16 *lo, int idx, f32x4 v) {
+    const f16x4 h = __builtin_convertvector(v, f16x4);                  // 2 x v_cvt_pk_f16_f32 (round to nearest even)
+    const f32x4 back = __builtin_convertvector(h, f32x4);
+    const f16x4 l = __builtin_convertvector((v - back) * SPLIT, f16x4);
+    *reinterpret_cast<f16x4 *>(hi + idx) = h;
+    *reinterpret_cast<f16x4 *>(lo + idx) = l;
 }
 
 // B operand of one conv: 10 coalesced 16-byte loads per lane.  Issued BEFORE the activation writes and the barrier that
@@ -286,57 +298,127 @@ __device__ __forceinline__ void load_wsplit(const uint4 *wp, int lane, f16x8 (&w
     }
 }
 
-// am[s] = conv of the wave's tiles (slots 0..5 = tiles wave + 4 s; slot 6 = this wave's K-steps of tile 24).  The
-// correction accumulators live only for the pair of tiles in flight.
-template <bool INIT_BIAS>
-__device__ __forceinline__ void conv3x3s(const _Float16 *hi, const _Float16 *lo, const f16x8 (&wh)[5], const f16x8 (&wl)[5],
-                                         float bias, const int (&base)[7], const int (&koff)[5], int wave, f32x4 (&am)[7]) {
-#pragma unroll
-    for (int s = 0; s < 6; s += 2) {
-        f32x4 m0 = INIT_BIAS ? f32x4{bias, bias, bias, bias} : f32x4{0.f, 0.f, 0.f, 0.f}, m1 = m0;
-        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            const f16x8 h0 = *reinterpret_cast<const f16x8 *>(hi + base[s] + koff[c]);
-            const f16x8 h1 = *reinterpret_cast<const f16x8 *>(hi + base[s + 1] + koff[c]);
-            const f16x8 l0 = *reinterpret_cast<const f16x8 *>(lo + base[s] + koff[c]);
-            const f16x8 l1 = *reinterpret_cast<const f16x8 *>(lo + base[s + 1] + koff[c]);
-            m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, wh[c], m0, 0, 0, 0);
-            m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, wh[c], m1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(l0, wh[c], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(l1, wh[c], c1, 0, 0, 0);
-            c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h0, wl[c], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h1, wl[c], c1, 0, 0, 0);
-            if (c & 1) __builtin_amdgcn_sched_barrier(0);        // at most two K-steps of A fragments in flight (registers)
-        }
+// am[s] = conv of the wave's tiles (slots 0..5 = tiles wave + 4 s; slot 6 = this wave's K-steps of tile 24), TRANSPOSED:
+// the weights are the matrix instruction's A operand and the activations its B operand, so a lane of the result holds
+// four consecutive output CHANNELS (4 g + r) of ONE position (tile position lane & 15) -- the split activations of a tile
+// are then two 8-byte LDS stores per lane instead of eight 2-byte ones, and the conversions pack in pairs.
+// The fragments of the next K-step are requested before the matrix instructions of the current one are issued (one wave
+// per SIMD when a board is alone on its CU: nothing else hides the LDS latency); the correction accumulators live only
+// for the pair of tiles in flight.
+// K-step c of a lane reads tap 2 c + (g >> 1), channels 8 (g & 1) .. + 7.  The tap's offset is A_c + (g >> 1) D_c positions
+// with A = {0, 2, SPW + 1, 2 SPW, 2 SPW + 2} and D = {1, SPW - 2, 1, 1, 0}: three lane-dependent bases per tile (D = 1, D = SPW - 2,
+// D = 0) and everything else is an immediate of the ds_read -- no address arithmetic between the matrix instructions
+// (one wave per SIMD issues a vector instruction every ~5 cycles; eight adds per K-step did not fit the MFMAs' gaps).
+struct SBase { const _Float16 *p1, *p10, *p0; };
+#ifndef TRL_PFD
+#define TRL_PFD 1
+#endif
+constexpr int PFD = TRL_PFD;       // K-steps between a fragment's ds_read and the matrix instructions that consume it
+template <int C> __device__ __forceinline__ const _Float16 *sb_ptr(const SBase &b) {
+    constexpr int A[5] = {0, 2, SPW + 1, 2 * SPW, 2 * SPW + 2};
+    return (C == 1 ? b.p10 : (C == 4 ? b.p0 : b.p1)) + A[C] * HST;
+}
+template <int C> __device__ __forceinline__ void sb_load(const SBase &b, f16x8 &h, f16x8 &l) {
+    const _Float16 *p = sb_ptr<C>(b);
+    h = *reinterpret_cast<const f16x8 *>(p);
+    l = *reinterpret_cast<const f16x8 *>(p + LO_OFS);
+}
+
+template <bool INIT_BIAS, bool ILV, int I>
+__device__ __forceinline__ void conv_step(const SBase (&sb)[7], const f16x8 (&wh)[5], const f16x8 (&wl)[5], f32x4 bias,
+                                          f16x8 (&h0)[PFD + 1], f16x8 (&h1)[PFD + 1], f16x8 (&l0)[PFD + 1], f16x8 (&l1)[PFD + 1],
+                                          f32x4 &m0, f32x4 &m1, f32x4 &c0, f32x4 &c1, f32x4 (&am)[7]) {
+    constexpr int s = 2 * (I / 5), c = I % 5, cur = I % (PFD + 1);
+    if (c == 0) {
+        m0 = INIT_BIAS ? bias : f32x4{0.f, 0.f, 0.f, 0.f}; m1 = m0;
+        c0 = f32x4{0.f, 0.f, 0.f, 0.f}; c1 = c0;
+    }
+    // one fragment request in the shadow of each of the first four matrix instructions: four ds_read_b128 issued in a row
+    // held the wave's issue for ~25 cycles per K-step (scripts/mfma16_pattern.hip: 126 -> 101 cycles per step, one wave per SIMD)
+    // (ILV: the variant for one board per CU; with two waves per SIMD the other wave's matrix instructions cover the
+    // issue of a group of four reads, and grouped requests measured 5 % faster at 1024+ boards)
+    constexpr bool LD = I + PFD < 15;
+    constexpr int sn = LD ? 2 * ((I + PFD) / 5) : 0, cn = LD ? (I + PFD) % 5 : 0, nxt = (I + PFD) % (PFD + 1);
+    if constexpr (LD && !ILV) {
+        sb_load<cn>(sb[sn], h0[nxt], l0[nxt]);
+        sb_load<cn>(sb[sn + 1], h1[nxt], l1[nxt]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], h0[cur], m0, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LD && ILV) h0[nxt] = *reinterpret_cast<const f16x8 *>(sb_ptr<cn>(sb[sn]));
+    __builtin_amdgcn_sched_barrier(0);
+    m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], h1[cur], m1, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LD && ILV) h1[nxt] = *reinterpret_cast<const f16x8 *>(sb_ptr<cn>(sb[sn + 1]));
+    __builtin_amdgcn_sched_barrier(0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], l0[cur], c0, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LD && ILV) l0[nxt] = *reinterpret_cast<const f16x8 *>(sb_ptr<cn>(sb[sn]) + LO_OFS);
+    __builtin_amdgcn_sched_barrier(0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], l1[cur], c1, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (LD && ILV) l1[nxt] = *reinterpret_cast<const f16x8 *>(sb_ptr<cn>(sb[sn + 1]) + LO_OFS);
+    __builtin_amdgcn_sched_barrier(0);
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c], h0[cur], c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c], h1[cur], c1, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (c == 4) {
         am[s] = m0 + c0 * INV_SPLIT;
         am[s + 1] = m1 + c1 * INV_SPLIT;
     }
+    if constexpr (I + 1 < 15) conv_step<INIT_BIAS, ILV, I + 1>(sb, wh, wl, bias, h0, h1, l0, l1, m0, m1, c0, c1, am);
+}
+
+template <int C> __device__ __forceinline__ void tile24_step(const SBase &b, const f16x8 (&wh)[5], const f16x8 (&wl)[5], int wave,
+                                                             f32x4 &m, f32x4 &cc) {
+    if ((C < 2 ? 0 : C - 1) == wave) {
+        f16x8 h, l;
+        sb_load<C>(b, h, l);
+        m = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[C], h, m, 0, 0, 0);
+        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[C], l, cc, 0, 0, 0);
+        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[C], h, cc, 0, 0, 0);
+    }
+    if constexpr (C + 1 < 5) tile24_step<C + 1>(b, wh, wl, wave, m, cc);
+}
+
+// am[s] = conv of the wave's tiles (slots 0..5 = tiles wave + 4 s; slot 6 = this wave's K-steps of tile 24), TRANSPOSED:
+// the weights are the matrix instruction's A operand and the activations its B operand, so a lane of the result holds
+// four consecutive output CHANNELS (4 g + r) of ONE position (tile position lane & 15) -- the split activations of a tile
+// are then two 8-byte LDS stores per lane instead of eight 2-byte ones, and the conversions pack in pairs.
+// The fragments of the next K-step are requested before the matrix instructions of the current one are issued (one wave
+// per SIMD when a board is alone on its CU: nothing else hides the LDS latency); the correction accumulators live only
+// for the pair of tiles in flight.
+template <bool INIT_BIAS, bool ILV>
+__device__ __forceinline__ void conv3x3s(const SBase (&sb)[7], const f16x8 (&wh)[5], const f16x8 (&wl)[5], f32x4 bias, int wave,
+                                         f32x4 (&am)[7]) {
+    f16x8 h0[PFD + 1], h1[PFD + 1], l0[PFD + 1], l1[PFD + 1];
+    sb_load<0>(sb[0], h0[0], l0[0]);
+    sb_load<0>(sb[1], h1[0], l1[0]);
+    if constexpr (PFD == 2) {
+        sb_load<1>(sb[0], h0[1], l0[1]);
+        sb_load<1>(sb[1], h1[1], l1[1]);
+    }
+    f32x4 m0, m1, c0, c1;
+    conv_step<INIT_BIAS, ILV, 0>(sb, wh, wl, bias, h0, h1, l0, l1, m0, m1, c0, c1, am);
     // tile 24 (25 tiles do not divide by 4 waves): its 5 K-steps are shared out 2 / 1 / 1 / 1 and summed through LDS
     f32x4 m = {0.f, 0.f, 0.f, 0.f}, cc = m;
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        if ((c < 2 ? 0 : c - 1) != wave) continue;
-        const f16x8 h = *reinterpret_cast<const f16x8 *>(hi + base[6] + koff[c]);
-        const f16x8 l = *reinterpret_cast<const f16x8 *>(lo + base[6] + koff[c]);
-        m = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, wh[c], m, 0, 0, 0);
-        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(l, wh[c], cc, 0, 0, 0);
-        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, wl[c], cc, 0, 0, 0);
-    }
+    tile24_step<0>(sb[6], wh, wl, wave, m, cc);
     am[6] = m + cc * INV_SPLIT;
 }
 
-template <int MINB>
+template <int MINB, bool ILV>
 __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *__restrict__ boards, const float *__restrict__ wts,
-                                                               int n_blocks, float *__restrict__ out,
-                                                               const uint8_t *__restrict__ need) {
+                                                                  int n_blocks, float *__restrict__ out,
+                                                                  const uint8_t *__restrict__ need) {
     if (need && !need[blockIdx.x]) return;
+    TPROF_T(tp_start);
     __builtin_amdgcn_s_setprio(3);
-    __shared__ __attribute__((aligned(16))) float lds[HPLANE + BW * BH + 4 * 256];      // 2 planes of halves = HPLANE floats
-    _Float16 *hiP = reinterpret_cast<_Float16 *>(lds), *loP = hiP + HPLANE;
+    __shared__ __attribute__((aligned(16))) float lds[HPLANE + BW * BH + 4 * 256];
+    _Float16 *hiP = reinterpret_cast<_Float16 *>(lds), *loP = hiP + LO_OFS;
     float *brd = lds + HPLANE, *part = lds + HPLANE + BW * BH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, co = lane & 15;
+    const int g = lane >> 4, pn = lane & 15;      // result layout: channels 4 g + r of tile position pn
     const size_t board = blockIdx.x;
 
     for (int i = tid; i < (HPLANE + BW * BH + 4 * 256) / 4; i += TRUNK_THREADS)
@@ -345,32 +427,20 @@ __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *_
     for (int i = tid; i < 400; i += TRUNK_THREADS) brd[(i / 10 + 2) * BW + (i % 10) + 2] = boards[board * 400 + i];
     __syncthreads();
 
-    int base[7];                    // offset (in halves) of the 3x3 window's top-left position of the lane's A row
+    SBase sb[7];                    // the lane's position in tile s: bases of its 3x3 window in the hi plane (see SBase)
+    int wofs[7];                    // where the lane's four channels of that position go in the planes
 #pragma unroll
     for (int s = 0; s < 7; s++) {
         const int T = (s < 6) ? wave + 4 * s : NT - 1;
-        const int p = 16 * T + (lane & 15);
-        base[s] = ((p / 10) * PW + (p % 10)) * HST;
-    }
-    // where a lane's C/D values go in the planes: rows 4 g + r of tile T are the four consecutive positions q .. q + 3,
-    // q = 16 T + 4 g; they stay in one board row unless q % 10 == 8 (then r = 2, 3 are in the next row: + 2 padding cells).
-    // One offset per slot and a wrap mask instead of 28 loop-invariant addresses (which cost 28 registers)
-    int wofs[7], wrapmask = 0;
-#pragma unroll
-    for (int s = 0; s < 7; s++) {
-        const int T = (s < 6) ? wave + 4 * s : NT - 1;
-        const int q = 16 * T + 4 * g;
-        wofs[s] = ((q / 10 + 1) * PW + (q % 10) + 1) * HST + co;
-        if (q % 10 == 8) wrapmask |= 1 << s;
-    }
-    int koff[5];                    // K-step c of this lane: tap 2 c + (g >> 1), channels 8 (g & 1) .. + 7
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        int tap = 2 * c + (g >> 1); if (tap > 8) tap = 8;            // the tenth half-step: zero weights, any finite data
-        koff[c] = ((tap / 3) * PW + (tap % 3)) * HST + 8 * (g & 1);
+        const int p = 16 * T + pn;
+        const _Float16 *b = hiP + ((p / 10) * SPW + (p % 10)) * HST + 8 * (g & 1);
+        sb[s].p0 = b; sb[s].p1 = b + (g >> 1) * HST; sb[s].p10 = b + (g >> 1) * (SPW - 2) * HST;
+        wofs[s] = ((p / 10 + 1) * SPW + (p % 10) + 1) * HST + 4 * g;
     }
 
-    // 5x5 stem, one input channel: im2col GEMM on the fp32 matrix instruction as in k_trunk16 (7 MFMAs per tile, once)
+    // 5x5 stem, one input channel: im2col GEMM on the fp32 matrix instruction as in k_trunk16 (7 per tile, once), with the
+    // operands swapped like the convs': A = w1[channel = lane & 15][tap 4 st + g], B = board value under that tap at the
+    // lane's position
     f32x4 x[7];
     {
         float wB[7];
@@ -378,16 +448,16 @@ __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *_
 #pragma unroll
         for (int st = 0; st < 7; st++) {
             const int t = 4 * st + g, tc = t < 25 ? t : 24;
-            wB[st] = t < 25 ? wts[co * 25 + tc] : 0.f;
+            wB[st] = t < 25 ? wts[pn * 25 + tc] : 0.f;
             toff[st] = (tc / 5) * BW + (tc % 5);
         }
 #pragma unroll
         for (int s = 0; s < 7; s++) {
             int T = wave + 4 * s; if (T >= NT) T = NT - 1;
-            const int p = 16 * T + (lane & 15), pb = (p / 10) * BW + (p % 10);
+            const int p = 16 * T + pn, pb = (p / 10) * BW + (p % 10);
             f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int st = 0; st < 7; st++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(brd[pb + toff[st]], wB[st], c, 0, 0, 0);
+            for (int st = 0; st < 7; st++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[st], brd[pb + toff[st]], c, 0, 0, 0);
             x[s] = c;
         }
     }
@@ -395,48 +465,63 @@ __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *_
     const float *wb = wts + 400;
     f32x4 am[7];
     f16x8 wh[5], wl[5];
+#ifdef TRL_PROFILE
+    unsigned long long tprof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    TPROF_T(tp_begin);
     for (int b = 0; b < n_blocks; b++, wb += WBLOCK_S) {
-        const float s1 = wb[co], t1 = wb[16 + co], bias_a = wb[32 + WCONV_S + co];
+        TPROF_T(tp0);
+        const f32x4 s1 = *reinterpret_cast<const f32x4 *>(wb + 4 * g), t1 = *reinterpret_cast<const f32x4 *>(wb + 16 + 4 * g);
+        const f32x4 bias_a = *reinterpret_cast<const f32x4 *>(wb + 32 + WCONV_S + 4 * g);
         load_wsplit(reinterpret_cast<const uint4 *>(wb + 32), lane, wh, wl);
 #pragma unroll
         for (int s = 0; s < 7; s++) {                               // H1 = relu(bn1(x)), split, own positions
             if (s < 6 || wave == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    store_split(hiP, loP, wofs[s] + r * HST + ((r >= 2 && ((wrapmask >> s) & 1)) ? 2 * HST : 0),
-                                fmaxf(fmaf(x[s][r], s1, t1), 0.f));
+                f32x4 v = x[s] * s1 + t1;
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                store_split4(hiP, loP, wofs[s], v);
             }
         }
+        TPROF_T(tp1);
         __syncthreads();
+        TPROF_T(tp2);
         __builtin_amdgcn_s_setprio(0);
-        conv3x3s<true>(hiP, loP, wh, wl, bias_a, base, koff, wave, am);
+        conv3x3s<true, ILV>(sb, wh, wl, bias_a, wave, am);
         __builtin_amdgcn_s_setprio(3);
         *reinterpret_cast<f32x4 *>(part + wave * 256 + lane * 4) = am[6];
         load_wsplit(reinterpret_cast<const uint4 *>(wb + 32 + WCONV_S + 16), lane, wh, wl);      // conv B's weights
+        TPROF_T(tp3);
         __syncthreads();                              // every wave has read its halo: the planes can be overwritten
+        TPROF_T(tp4);
         if (wave == 0) {
             f32x4 t = *reinterpret_cast<const f32x4 *>(part + lane * 4);
             t += *reinterpret_cast<const f32x4 *>(part + 256 + lane * 4);
             t += *reinterpret_cast<const f32x4 *>(part + 512 + lane * 4);
             t += *reinterpret_cast<const f32x4 *>(part + 768 + lane * 4);
-            am[6] = t + f32x4{bias_a, bias_a, bias_a, bias_a};
+            am[6] = t + bias_a;
         }
 #pragma unroll
         for (int s = 0; s < 7; s++) {
             if (s < 6 || wave == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    store_split(hiP, loP, wofs[s] + r * HST + ((r >= 2 && ((wrapmask >> s) & 1)) ? 2 * HST : 0), fmaxf(am[s][r], 0.f));
+                f32x4 v = am[s];
+                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+                store_split4(hiP, loP, wofs[s], v);
             }
         }
+        TPROF_T(tp5);
         __syncthreads();
+        TPROF_T(tp6);
         __builtin_amdgcn_s_setprio(0);
-        conv3x3s<false>(hiP, loP, wh, wl, 0.f, base, koff, wave, am);
+        conv3x3s<false, ILV>(sb, wh, wl, f32x4{0.f, 0.f, 0.f, 0.f}, wave, am);
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int s = 0; s < 6; s++) x[s] += am[s];
         *reinterpret_cast<f32x4 *>(part + wave * 256 + lane * 4) = am[6];
+        TPROF_T(tp7);
         __syncthreads();
+        TPROF_T(tp8);
+        TPROF_ADD(0, tp0, tp1); TPROF_ADD(1, tp1, tp2); TPROF_ADD(2, tp2, tp3); TPROF_ADD(3, tp3, tp4); TPROF_ADD(4, tp4, tp5);
+        TPROF_ADD(5, tp5, tp6); TPROF_ADD(6, tp6, tp7); TPROF_ADD(7, tp7, tp8);
         if (wave == 0) {
             f32x4 t = *reinterpret_cast<const f32x4 *>(part + lane * 4);
             t += *reinterpret_cast<const f32x4 *>(part + 256 + lane * 4);
@@ -445,17 +530,26 @@ __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *_
             x[6] += t;
         }
     }
-    // tail: relu(bn(x)) -> 1x1 conv over the 16 channels (= 16 lanes) -> folded bn -> relu   (fp32, as k_trunk16)
-    const float s = wb[co], t = wb[16 + co], wk = wb[32 + co], bk = wb[48];
+#ifdef TRL_PROFILE
+    {
+        TPROF_T(tp_end);
+        tprof[8] = tp_end - tp_begin; tprof[9] = tp_begin - tp_start;
+        if ((blockIdx.x == 0 || blockIdx.x == 300) && lane == 0)
+            for (int i = 0; i < 10; i++) g_tprof[((blockIdx.x ? 1 : 0) * 8 + wave) * 10 + i] = tprof[i];
+    }
+#endif
+    // tail: relu(bn(x)) -> 1x1 conv over the 16 channels (4 in the lane, 4 lane groups) -> folded bn -> relu   (fp32)
+    const f32x4 s = *reinterpret_cast<const f32x4 *>(wb + 4 * g), t = *reinterpret_cast<const f32x4 *>(wb + 16 + 4 * g);
+    const f32x4 wk = *reinterpret_cast<const f32x4 *>(wb + 32 + 4 * g);
+    const float bk = wb[48];
 #pragma unroll
     for (int sidx = 0; sidx < 7; sidx++) {
         const int T = wave + 4 * sidx;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            float v = fmaxf(fmaf(x[sidx][r], s, t), 0.f) * wk;
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-            if (co == 0 && T < NT) out[board * 400 + 16 * T + 4 * g + r] = fmaxf(v + bk, 0.f);
-        }
+        f32x4 y = x[sidx] * s + t;
+        float v = fmaxf(y[0], 0.f) * wk[0];
+        v = fmaf(fmaxf(y[1], 0.f), wk[1], v); v = fmaf(fmaxf(y[2], 0.f), wk[2], v); v = fmaf(fmaxf(y[3], 0.f), wk[3], v);
+        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+        if (g == 0 && T < NT) out[board * 400 + 16 * T + pn] = fmaxf(v + bk, 0.f);
     }
 }
 
@@ -1056,13 +1150,15 @@ int trl_alphasame_trunk16_split(const float *dev_boards, int n_boards, const flo
                                 float *dev_out, const uint8_t *dev_need, void *stream) {
     if (!dev_boards || !dev_packed || !dev_out || n_boards <= 0 || n_blocks < 0)
         return fail(TRL_E_INVALID, "trl_alphasame_trunk16_split: %s", "bad argument");
-    static const int occ = getenv("TRL_SPLIT_OCC") ? atoi(getenv("TRL_SPLIT_OCC")) : 2;       // probe knob (3: 168 VGPRs, spills)
-    if (occ == 2)
-        hipLaunchKernelGGL(k_trunk16s<2>, dim3(n_boards), dim3(TRUNK_THREADS), 0, (hipStream_t)stream, dev_boards, dev_packed,
-                           n_blocks, dev_out, dev_need);
+    // up to one board per CU the fragment reads are interleaved with the matrix instructions, beyond that grouped (see
+    // conv_step); TRL_SPLIT_ILV = 0 / 1 forces one form (probe knob)
+    static const int force = getenv("TRL_SPLIT_ILV") ? atoi(getenv("TRL_SPLIT_ILV")) : -1;
+    if (force < 0 ? n_boards <= 256 : force != 0)
+        hipLaunchKernelGGL((k_trunk16s<2, true>), dim3(n_boards), dim3(TRUNK_THREADS), 0, (hipStream_t)stream, dev_boards,
+                           dev_packed, n_blocks, dev_out, dev_need);
     else
-        hipLaunchKernelGGL(k_trunk16s<3>, dim3(n_boards), dim3(TRUNK_THREADS), 0, (hipStream_t)stream, dev_boards, dev_packed,
-                           n_blocks, dev_out, dev_need);
+        hipLaunchKernelGGL((k_trunk16s<2, false>), dim3(n_boards), dim3(TRUNK_THREADS), 0, (hipStream_t)stream, dev_boards,
+                           dev_packed, n_blocks, dev_out, dev_need);
     HIPCHK(hipGetLastError());
     return TRL_OK;
 }

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "trl_env_rollout_random", "trl_last_kernel_ms",
     "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_expand_head", "trl_mcts_drain_records", "trl_mcts_drain_records_dev", "trl_mcts_get_stats",
     "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16", "trl_alphasame_trunk16_need", "trl_alphasame_trunk16_split", "trl_trunk_wide_split", "trl_alphasame_trunk", "trl_resnet_trunk", "trl_graph_begin", "trl_graph_end", "trl_graph_launch",
-    "trl_mcts_select_need", "trl_mcts_expand_alphasame_masked", "trl_mcts_zcache", "trl_mcts_zcache_dim", "trl_mcts_expand_alphasame",
+    "trl_mcts_select_need", "trl_mcts_fork_legal", "trl_mcts_expand_alphasame_masked", "trl_mcts_zcache", "trl_mcts_zcache_dim", "trl_mcts_expand_alphasame",
 ]
 
 GRID_FLOATS = 400
@@ -132,6 +132,7 @@ def load_library(path=None):
     L.trl_mcts_leaf_states.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.trl_mcts_root_children.argtypes = [C.c_void_p] + [C.c_void_p] * 5
     L.trl_mcts_select_need.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.trl_mcts_fork_legal.argtypes = [C.c_void_p, C.c_int]
     L.trl_mcts_zcache.argtypes = [C.c_void_p, C.c_void_p]
     L.trl_mcts_zcache_dim.argtypes = [C.c_void_p, C.c_int]
     L.trl_graph_begin.argtypes = [C.c_void_p]
@@ -265,6 +266,9 @@ class Engine:
 
     def mcts_select_need(self, grids_ptr, vec_ptr, need_ptr):
         _check(self._L, self._L.trl_mcts_select_need(self._h, grids_ptr, vec_ptr, need_ptr), "trl_mcts_select_need")
+
+    def mcts_fork_legal(self, on=True):
+        _check(self._L, self._L.trl_mcts_fork_legal(self._h, int(bool(on))), "trl_mcts_fork_legal")
 
     def graph_begin(self):
         _check(self._L, self._L.trl_graph_begin(self._h), "trl_graph_begin")

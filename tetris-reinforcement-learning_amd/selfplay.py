@@ -123,7 +123,8 @@ class SelfPlay:
     """n_slots concurrent self-play games: Engine + net + HIP-graph tick."""
 
     def __init__(self, config, network, n_slots, seed=0, device=0, streams=None, auto_reset=True, use_graph=True,
-                 max_nodes=0, record_capacity=0, policy_head="legal", tower_cache=True, device_heads=True, episodes=(0, 0)):
+                 max_nodes=0, record_capacity=0, policy_head="legal", tower_cache=True, device_heads=True, episodes=(0, 0),
+                 fork_legal=None):
         """policy_head: "legal" = only the legal moves' logits are formed, inside the expand kernel
         (trl_mcts_expand_head); "full" = the reference's data flow, softmax over all 11 583 logits."""
         if policy_head not in ("legal", "full"):
@@ -157,6 +158,13 @@ class SelfPlay:
         if self.heads is not None:
             with torch.cuda.stream(self.stream):
                 self.z = torch.zeros((2 * self.n, _eng.GRID_FLOATS), dtype=torch.float32, device=self.device)
+        # the leaf's legal-move search beside the tower (trl_mcts_fork_legal), opt-in (TRL_FORK_LEGAL=1): bit-identical, but
+        # measured no faster -- 0.249 against 0.242 ms per C3 tick: the search waves take from the tower what they save
+        if fork_legal is None:
+            fork_legal = os.environ.get("TRL_FORK_LEGAL", "0") != "0"
+        self.fork_legal = bool(fork_legal) and self.tower_cache
+        if self.fork_legal:
+            self.engine.mcts_fork_legal(True)
         self.stream.synchronize()
         self.graph = None
         self.native_graph = False
