@@ -59,3 +59,20 @@ def wsim(PW):
         t+=wcycles(addrs)
     return t/25
 for PW in (12,26): print("write PW",PW,wsim(PW),"(2 = conflict-free)")
+print("---- wide split tower: oct-planes of [rows x pitch positions][8 halves], lane (m, g) reads plane g")
+def sim_wide(PW, plane_bytes):
+    total=0; n=0
+    for T in range(25):
+        for tap in range(9):
+            addrs=[]
+            for lane in range(64):
+                m=lane&15; g=lane>>4
+                p=16*T+m
+                pos=(p//10+tap//3)*PW+p%10+tap%3
+                addrs.append(g*plane_bytes+pos*16)
+            total+=cycles(addrs); n+=1
+    return total/n
+for PW,pb in ((12,8192),(26,42*26*16),(26,42*26*16+64),(26,42*26*16+128)):
+    print("pitch",PW,"plane bytes",pb, round(sim_wide(PW,pb),2))
+for PW,pb in ((26,17664),(12,8192+0),(18,42*18*16),(18,12288)):
+    print("pitch",PW,"plane bytes",pb, round(sim_wide(PW,pb),2))

@@ -1,22 +1,27 @@
-"""timing of the 64-filter tower for several builds of the library (one process each)"""
-import sys, os, subprocess, time
-if len(sys.argv) > 2 or (len(sys.argv) == 2 and not sys.argv[1].startswith("--one=")):
-    for lib in sys.argv[1:]:
-        subprocess.run([sys.executable, os.path.abspath(__file__), "--one=" + lib])
-    sys.exit(0)
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""timing experiments on the split wide tower: python scripts/wide_exp.py <library built with -DTRL_EXP=n> ...
+(TRL_EXP = 1: weights not re-read per K-step; 2: fragments not re-read; 3: one tile's split + write only -- results are
+wrong, the time shows what that ingredient costs)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch
 import tetris_rl_amd as trl
 from tetris_rl_amd import engine
-lib = sys.argv[1][6:]
-engine._lib = engine.load_library(os.path.abspath(lib))
+if len(sys.argv) > 1:
+    engine._lib = engine.load_library(sys.argv[1])
 torch.manual_seed(0)
-for blocks, filters in ((20, 64), (10, 32)):
-    net = trl.AlphaSame(trl.AlphaSameConfig(blocks=blocks, filters=filters)).cuda().prepare()
-    boards = (torch.rand((2048, 1, 40, 10), device="cuda") < 0.3).float()
-    for _ in range(2): net.trunk(boards)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(5): net.trunk(boards)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
-    flop = 2048 * (2 * blocks * 400 * 9 * filters * filters * 2 + 400 * 25 * filters * 2)
-    print("%-24s b%df%d: %.2f ms, %.1f TFLOP/s" % (os.path.basename(lib), blocks, filters, dt * 1e3, flop / dt / 1e12), flush=True)
+net = trl.AlphaSame(trl.AlphaSameConfig(blocks=20, filters=64)).cuda().prepare()
+net16 = trl.AlphaSame(trl.AlphaSameConfig(blocks=10, filters=16)).cuda().prepare()
+boards = (torch.rand((1024, 1, 40, 10), device="cuda") < 0.3).float()
+for name, m in (("b20f64", net), ("b10f16", net16)):
+    line = []
+    for n in (256, 1024):
+        b = boards[:n].contiguous()
+        m.trunk(b); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            m.trunk(b)
+        e1.record(); torch.cuda.synchronize()
+        line.append("%d: %.3f ms" % (n, e0.elapsed_time(e1) / 10))
+    print(sys.argv[1] if len(sys.argv) > 1 else "default", name, "  ".join(line), flush=True)

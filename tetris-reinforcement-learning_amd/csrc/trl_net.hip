@@ -34,6 +34,9 @@ __device__ unsigned long long g_tprof[2 * 8 * 10];  // [workgroup 0 | 1500][wave
 #define TPROF_ADD(i, a, b)
 #endif
 
+#ifndef TRL_EXP
+#define TRL_EXP 0          // scripts/wide_exp.py: timing experiments that leave out one ingredient of a kernel (wrong results)
+#endif
 constexpr int F = 16;
 constexpr int PW = 12, PH = 42;                 // padded activation plane (1-cell zero border)
 constexpr int STRIDE = 16;                      // floats per position
@@ -730,7 +733,7 @@ __global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float
         // conv input -> planes (own positions): the block input (pre-activation: through bn1 + relu) for the first
         // conv, relu(previous conv) for the second
 #pragma unroll
-        for (int s = 0; s < TS; s++) {
+        for (int s = 0; s < (TRL_EXP == 3 ? 1 : TS); s++) {
             int T = mq + MSPLIT * s;
             if (T < NT) {
                 const uint2 o = otab[4 * T + g];
@@ -821,274 +824,268 @@ __global__ __launch_bounds__(Wide<FF>::THREADS, 2) void k_trunk_wide(const float
 
 // ---- wide towers on the f16 matrix rate with split operands (see k_trunk16s): k_trunk_wide_s<32|64> -----------------
 // Same scheme as k_trunk16s -- a = hi + lo / 2^11, three v_mfma_f32_16x16x32_f16 per product, fp32 accumulation -- on the
-// data flow of k_trunk_wide (weights streamed from L2 one K-step ahead and reused by all M-tiles of the wave; residual
-// stream and accumulators in registers), one wave per N-tile.  K = 9 taps x FF channels in 9 FF/32 K-steps
-// of 32 channels of one tap (no padding: 576 = 18 x 32): 54 matrix instructions of 16 cycles per (tile, N-tile, conv) at
-// FF = 64 instead of 144 of 32 cycles.
-//   * activations: hi and lo planes of halves, FF/8 "oct-planes" [42 x 12 padded positions][8 channels] each (8 KB): the
-//     A fragment of a lane (position m, channels 8 g .. 8 g + 7 of the K-step's 32) is ONE ds_read_b128 from plane 4 kg + g,
-//     consecutive lanes read consecutive 16-byte cells; FF = 64: 2 x 64 KB -- the size of the fp32 planes;
-//   * packed weights (nets._pack_conv3x3_split_wide): [K-step = kg * 9 + tap][hi | lo][N-tile][lane][8 halves], lane
-//     (n, g) holds W[16 ntile + n][32 kg + 8 g + j][tap]; 147 KB per conv at FF = 64, as many bytes as the fp32 layout.
-// MS = 1: one wave per N-tile carrying all 25 M-tiles -- one wave per SIMD, the whole 512-entry register file (residual
-//         stream, main and correction accumulators = 300 registers), every weight crosses the L2 once per conv and board;
-// MS = 2: two waves per N-tile (even / odd M-tiles, as k_trunk_wide) -- two waves per SIMD with 256 registers each.
-template <int FF, int MS = 1> struct WideS {
-    static constexpr int NN = FF / 16, KG = FF / 32, WAVES = MS * NN, MSPLIT = MS, TS = (NT + MSPLIT - 1) / MSPLIT;
+// data flow of k_trunk_wide (weights streamed from L2 one K-step ahead and reused by all tiles of the wave; residual
+// stream and accumulators in registers).  K = 9 taps x FF channels in 9 FF/32 K-steps of 32 channels of one tap (no
+// padding: 576 = 18 x 32): 54 matrix instructions of 16 cycles per (tile, channel group, conv) at FF = 64 instead of 144
+// of 32 cycles.
+//   * 2 FF/16 waves: wave = cgroup + NN * mq owns the 16 output channels of group `cgroup` for the even (mq = 0: 13) or odd
+//     (mq = 1: 12) position tiles -- two waves per SIMD;
+//   * the result is TRANSPOSED as in k_trunk16s (weights = the instruction's A operand, activations = B): a lane holds
+//     channels 4 g + r of its group at tile position lane & 15, so a tile's split activations leave as two 8-byte LDS
+//     stores per lane (104 two-byte stores per lane and layer before: that phase, not the convs, was the largest single
+//     cost of the layer -- a quarter of the launch in a leave-one-out timing, scripts/wide_exp.py);
+//   * ONE accumulator per tile: with the weights' hi half scaled by 2^11 in registers (bs = 2048 bh, exact; |w| < 32 is
+//     checked by the packer) the three products bs hi_a, bh lo_a and bl hi_a all carry the factor 2^11 (lo = 2^11 (a - hi)
+//     on both sides), so the correction needs no accumulator of its own -- 52 registers, which hold a second fragment
+//     buffer instead: the fragments of the next group of 2-3 tiles are requested before the 6-9 matrix instructions of
+//     the current one (phase stamps showed a wave spending half of a conv waiting for the reads it had just issued);
+//   * activations: FF/8 "oct-planes" of halves, [42 rows][12 hi | 12 lo positions at a pitch of 26][8 channels] (17.25 KB):
+//     the fragment of a lane (position n, channels 8 g .. 8 g + 7 of the K-step's 32) is ONE ds_read_b128 from plane
+//     4 kg + g, the 16 positions of a tile on distinct banks although they span board rows (pitch 26 = 10 + 16, see SPW;
+//     separate hi / lo planes at pitch 12 took two LDS passes per read); FF = 64: 138 KB, one board per CU;
+//   * packed weights (nets._pack_conv3x3_split_wide): [K-step = kg * 9 + tap][hi | lo][channel group][lane][8 halves], lane
+//     (m, g) holds W[16 cgroup + m][32 kg + 8 g + j][tap]; 147 KB per conv at FF = 64, as many bytes as the fp32 layout.
+template <int FF> struct WideS {
+    static constexpr int NN = FF / 16, KG = FF / 32, WAVES = 2 * NN, TS = 13;
     static constexpr int THREADS = 64 * WAVES, OCT = FF / 8;
-    static constexpr int PLANEH = 4096;                    // halves per oct-plane: 504 positions x 8, padded to 8 KB
-    static constexpr int HALF_FLOATS = OCT * PLANEH / 2;   // floats of the hi (or lo) planes
-    static constexpr int LDS_FLOATS = 2 * HALF_FLOATS + BW * BH + 200;
+    // halves per oct-plane: 42 rows x SPW positions x 8 channels (hi at positions 0..11 of a row, lo at 13..24, as in
+    // k_trunk16s), padded to a multiple of 256 bytes: lanes 0-3 / 12-15 (plane g = 0) and 20-27 (plane g = 1) are served
+    // together, so the planes must sit a whole number of bank rounds apart for their cells to interleave
+    static constexpr int PLANEH = 8832, LO = 13 * 8;
+    static constexpr int PLANES_FLOATS = OCT * PLANEH / 2;
+    static constexpr int LDS_FLOATS = PLANES_FLOATS + BW * BH;
     static constexpr int KSTEPS = 9 * KG;
-    static constexpr int WSTEP = 2 * NN * 64 * 4;          // packed dwords per K-step (hi and lo, all N-tiles)
+    static constexpr int WSTEP = 2 * NN * 64 * 4;          // packed dwords per K-step (hi and lo, all channel groups)
     static constexpr int CONVW = KSTEPS * WSTEP;
 };
 
-// tiles of group G (of 6: 4, 4, 4, 4, 4, 5 of the 25 M-tiles)
-template <int G> struct WGrp { static constexpr int S0 = 4 * G, S1 = (G == 5) ? NT : 4 * G + 4, N = S1 - S0; };
+// tiles of group G (of 6) of a wave with NTL tiles: 2, 2, 2, 2, 2 and 2 or 3
+template <int NTL, int G> struct SGrp { static constexpr int S0 = 2 * G, S1 = (G == 5) ? NTL : 2 * G + 2, N = S1 - S0; };
 
-template <int G>
-__device__ __forceinline__ void wides_load(const _Float16 *ph, const _Float16 *pl, const int (&base)[NT], int off,
-                                           f16x8 (&ah)[5], f16x8 (&al)[5]) {
+template <int NTL, int G, int NB>
+__device__ __forceinline__ void wides_load(const _Float16 *ph, const _Float16 *pl, const int (&base)[13], int off,
+                                           f16x8 (&ah)[NB], f16x8 (&al)[NB]) {
 #pragma unroll
-    for (int s = WGrp<G>::S0; s < WGrp<G>::S1; s++) {
-        ah[s - WGrp<G>::S0] = *reinterpret_cast<const f16x8 *>(ph + base[s] + off);
-        al[s - WGrp<G>::S0] = *reinterpret_cast<const f16x8 *>(pl + base[s] + off);
+    for (int s = SGrp<NTL, G>::S0; s < SGrp<NTL, G>::S1; s++) {
+        ah[s - SGrp<NTL, G>::S0] = *reinterpret_cast<const f16x8 *>(ph + base[s] + off);
+        al[s - SGrp<NTL, G>::S0] = *reinterpret_cast<const f16x8 *>(pl + base[s] + off);
     }
 }
-template <int G>
-__device__ __forceinline__ void wides_mfma(const f16x8 (&ah)[5], const f16x8 (&al)[5], f16x8 bh, f16x8 bl, f32x4 (&am)[NT], f32x4 (&ac)[NT]) {
+template <int NTL, int G, int NB>
+__device__ __forceinline__ void wides_mfma(const f16x8 (&ah)[NB], const f16x8 (&al)[NB], f16x8 bs, f16x8 bh, f16x8 bl, f32x4 (&am)[13]) {
+    constexpr int S0 = SGrp<NTL, G>::S0, S1 = SGrp<NTL, G>::S1;
 #pragma unroll
-    for (int s = WGrp<G>::S0; s < WGrp<G>::S1; s++) am[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s - WGrp<G>::S0], bh, am[s], 0, 0, 0);
+    for (int s = S0; s < S1; s++) am[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bs, ah[s - S0], am[s], 0, 0, 0);
 #pragma unroll
-    for (int s = WGrp<G>::S0; s < WGrp<G>::S1; s++) ac[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s - WGrp<G>::S0], bh, ac[s], 0, 0, 0);
+    for (int s = S0; s < S1; s++) am[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[s - S0], am[s], 0, 0, 0);
 #pragma unroll
-    for (int s = WGrp<G>::S0; s < WGrp<G>::S1; s++) ac[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s - WGrp<G>::S0], bl, ac[s], 0, 0, 0);
+    for (int s = S0; s < S1; s++) am[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[s - S0], am[s], 0, 0, 0);
 }
 
-// am[s] (+)= conv of all 25 tiles; wh / wl = the first K-step's B operand (already in flight).
-// One wave per SIMD: nothing hides a stall but the wave's own instruction stream, so the A fragments are software-
-// pipelined one group ahead (two register buffers; six groups per K-step, so the buffer of a group is fixed) and the
-// weights one K-step ahead; each group issues 12-15 matrix instructions (192-240 cycles) over the next group's 8-10 reads.
-template <int FF>
+// am[s] += 2^11 conv of the wave's NTL tiles; wh / wl = the first K-step's weights (already in flight)
+template <int FF, int NTL>
 __device__ __forceinline__ void conv_wide_s(const _Float16 *hiL, const _Float16 *loL, const uint4 *wq, f16x8 wh, f16x8 wl,
-                                            const int (&base)[NT], f32x4 (&am)[NT], f32x4 (&ac)[NT]) {
+                                            const int (&base)[13], f32x4 (&am)[13]) {
     using W = WideS<FF>;
-    constexpr int STEPQ = W::WSTEP / 4;                    // uint4 per K-step
-    f16x8 ah0[5], al0[5], ah1[5], al1[5];
-    wides_load<0>(hiL, loL, base, 0, ah0, al0);
+    constexpr int STEPQ = W::WSTEP / 4;
+    f16x8 ah0[2], al0[2], ah1[3], al1[3];
+    wides_load<NTL, 0>(hiL, loL, base, 0, ah0, al0);
+#if TRL_EXP == 2
+    wides_load<NTL, 5>(hiL, loL, base, 0, ah1, al1);
+#endif
     for (int kg = 0; kg < W::KG; kg++) {
         const _Float16 *ph = hiL + kg * 4 * W::PLANEH, *pl = loL + kg * 4 * W::PLANEH;
 #pragma unroll 1
         for (int tap = 0; tap < 9; tap++) {
-            const f16x8 bh = wh, bl = wl;
+            const f16x8 bh = wh, bl = wl, bs = bh * (_Float16)SPLIT;
             wq += STEPQ;                                   // next K-step (the last prefetch of a conv reads what follows it: unused)
+#if TRL_EXP != 1
             wh = __builtin_bit_cast(f16x8, wq[0]);
             wl = __builtin_bit_cast(f16x8, wq[W::NN * 64]);
-            const int ty = tap / 3, off = (ty * PW + (tap - 3 * ty)) * 8;
-            const int tn = tap == 8 ? 0 : tap + 1, tny = tn / 3, offn = (tny * PW + (tn - 3 * tny)) * 8;
+#endif
+            const int ty = tap / 3, off = (ty * SPW + (tap - 3 * ty)) * 8;
+            const int tn = tap == 8 ? 0 : tap + 1, tny = tn / 3, offn = (tny * SPW + (tn - 3 * tny)) * 8;
             const _Float16 *phn = (tap == 8 && kg + 1 < W::KG) ? ph + 4 * W::PLANEH : ph;      // (the last prefetch of a conv is unused)
             const _Float16 *pln = (tap == 8 && kg + 1 < W::KG) ? pl + 4 * W::PLANEH : pl;
-            wides_load<1>(ph, pl, base, off, ah1, al1);
+#if TRL_EXP == 2
+            wides_mfma<NTL, 0>(ah0, al0, bs, bh, bl, am); wides_mfma<NTL, 1>(ah0, al0, bs, bh, bl, am);
+            wides_mfma<NTL, 2>(ah0, al0, bs, bh, bl, am); wides_mfma<NTL, 3>(ah0, al0, bs, bh, bl, am);
+            wides_mfma<NTL, 4>(ah0, al0, bs, bh, bl, am); wides_mfma<NTL, 5>(ah1, al1, bs, bh, bl, am);
             __builtin_amdgcn_sched_barrier(0);
-            wides_mfma<0>(ah0, al0, bh, bl, am, ac);
+            continue;
+#endif
+            wides_load<NTL, 1>(ph, pl, base, off, ah1, al1);
             __builtin_amdgcn_sched_barrier(0);
-            wides_load<2>(ph, pl, base, off, ah0, al0);
+            wides_mfma<NTL, 0>(ah0, al0, bs, bh, bl, am);
             __builtin_amdgcn_sched_barrier(0);
-            wides_mfma<1>(ah1, al1, bh, bl, am, ac);
+            wides_load<NTL, 2>(ph, pl, base, off, ah0, al0);
             __builtin_amdgcn_sched_barrier(0);
-            wides_load<3>(ph, pl, base, off, ah1, al1);
+            wides_mfma<NTL, 1>(ah1, al1, bs, bh, bl, am);
             __builtin_amdgcn_sched_barrier(0);
-            wides_mfma<2>(ah0, al0, bh, bl, am, ac);
+            wides_load<NTL, 3>(ph, pl, base, off, ah1, al1);
             __builtin_amdgcn_sched_barrier(0);
-            wides_load<4>(ph, pl, base, off, ah0, al0);
+            wides_mfma<NTL, 2>(ah0, al0, bs, bh, bl, am);
             __builtin_amdgcn_sched_barrier(0);
-            wides_mfma<3>(ah1, al1, bh, bl, am, ac);
+            wides_load<NTL, 4>(ph, pl, base, off, ah0, al0);
             __builtin_amdgcn_sched_barrier(0);
-            wides_load<5>(ph, pl, base, off, ah1, al1);
+            wides_mfma<NTL, 3>(ah1, al1, bs, bh, bl, am);
             __builtin_amdgcn_sched_barrier(0);
-            wides_mfma<4>(ah0, al0, bh, bl, am, ac);
+            wides_load<NTL, 5>(ph, pl, base, off, ah1, al1);
             __builtin_amdgcn_sched_barrier(0);
-            wides_load<0>(phn, pln, base, offn, ah0, al0);
+            wides_mfma<NTL, 4>(ah0, al0, bs, bh, bl, am);
             __builtin_amdgcn_sched_barrier(0);
-            wides_mfma<5>(ah1, al1, bh, bl, am, ac);
+            wides_load<NTL, 0>(phn, pln, base, offn, ah0, al0);
+            __builtin_amdgcn_sched_barrier(0);
+            wides_mfma<NTL, 5>(ah1, al1, bs, bh, bl, am);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
-// the same for the 12 or 13 tiles of a wave at MS = 2: two waves per SIMD cover each other's LDS latency, the A fragments
-// of a group of 4-5 tiles are read right before their 12-15 matrix instructions
-template <int FF, int NTL>
-__device__ __forceinline__ void conv_wide_s2(const _Float16 *hiL, const _Float16 *loL, const uint4 *wq, f16x8 wh, f16x8 wl,
-                                             const int (&base)[13], f32x4 (&am)[13], f32x4 (&ac)[13]) {
-    using W = WideS<FF, 2>;
-    constexpr int STEPQ = W::WSTEP / 4;
-    for (int kg = 0; kg < W::KG; kg++) {
-        const _Float16 *ph = hiL + kg * 4 * W::PLANEH, *pl = loL + kg * 4 * W::PLANEH;
-#pragma unroll 1
-        for (int tap = 0; tap < 9; tap++) {
-            const f16x8 bh = wh, bl = wl;
-            wq += STEPQ;
-            wh = __builtin_bit_cast(f16x8, wq[0]);
-            wl = __builtin_bit_cast(f16x8, wq[W::NN * 64]);
-            const int ty = tap / 3, off = (ty * PW + (tap - 3 * ty)) * 8;
-#pragma unroll
-            for (int s0 = 0; s0 < NTL; s0 += 4) {
-                const int s1 = (s0 + 8 > NTL) ? NTL : s0 + 4;          // 4, 4, 4 or 4, 4, 5 tiles
-                f16x8 ah[5], al[5];
-#pragma unroll
-                for (int s = s0; s < s1; s++) {
-                    ah[s - s0] = *reinterpret_cast<const f16x8 *>(ph + base[s] + off);
-                    al[s - s0] = *reinterpret_cast<const f16x8 *>(pl + base[s] + off);
-                }
-#pragma unroll
-                for (int s = s0; s < s1; s++) am[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s - s0], bh, am[s], 0, 0, 0);
-#pragma unroll
-                for (int s = s0; s < s1; s++) ac[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s - s0], bh, ac[s], 0, 0, 0);
-#pragma unroll
-                for (int s = s0; s < s1; s++) ac[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s - s0], bl, ac[s], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (s1 == NTL) break;
-            }
-        }
-    }
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    return v;
 }
 
-template <int FF, bool POST, int MS>
-__global__ __launch_bounds__((WideS<FF, MS>::THREADS), MS) void k_trunk_wide_s(const float *__restrict__ boards,
-                                                                        const float *__restrict__ wts, int n_blocks,
-                                                                        float *__restrict__ out,
-                                                                        const uint8_t *__restrict__ need, int kout) {
-    using W = WideS<FF, MS>;
-    constexpr int TS = W::TS, NN = W::NN, MSPLIT = W::MSPLIT, THREADS = W::THREADS;
-    constexpr int STEM = POST ? 9 : 25;
+template <int FF, bool POST>
+__global__ __launch_bounds__((WideS<FF>::THREADS), 2) void k_trunk_wide_s(const float *__restrict__ boards,
+                                                                       const float *__restrict__ wts, int n_blocks,
+                                                                       float *__restrict__ out,
+                                                                       const uint8_t *__restrict__ need, int kout) {
+    using W = WideS<FF>;
+    constexpr int TS = W::TS, NN = W::NN, THREADS = W::THREADS;
+    constexpr int STEM = POST ? 9 : 25, STEM_STEPS = (STEM + 3) / 4;
     if (need && !need[blockIdx.x]) return;
     __shared__ __attribute__((aligned(16))) float lds[W::LDS_FLOATS];
-    _Float16 *hiP = reinterpret_cast<_Float16 *>(lds), *loP = hiP + W::OCT * W::PLANEH;
-    float *brd = lds + 2 * W::HALF_FLOATS;
-    uint2 *otab = reinterpret_cast<uint2 *>(brd + BW * BH);   // otab[p / 4]: cell offsets (in halves) of positions p .. p + 3
+    _Float16 *hiP = reinterpret_cast<_Float16 *>(lds), *loP = hiP + W::LO;
+    float *brd = lds + W::PLANES_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, co = lane & 15;
-    const int ntile = wave % NN, mq = wave / NN;
-    const int ch = ntile * 16 + co;
+    const int g = lane >> 4, pn = lane & 15;              // result layout: channels 4 g + r of the group at tile position pn
+    const int cgroup = wave % NN, mq = wave / NN;
+    const int ch4 = cgroup * 16 + 4 * g;                  // the lane's first channel
     const size_t board = blockIdx.x;
 
     for (int i = tid; i < W::LDS_FLOATS / 4; i += THREADS) reinterpret_cast<f32x4 *>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     for (int i = tid; i < 400; i += THREADS) brd[(i / 10 + 2) * BW + (i % 10) + 2] = boards[board * 400 + i];
-    for (int i = tid; i < 100; i += THREADS) {
-        unsigned o[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) { int p = 4 * i + r; o[r] = ((p / 10 + 1) * PW + (p % 10) + 1) * 8; }
-        otab[i] = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
-    }
     __syncthreads();
 
-    int base[TS];                   // cell offset (in halves) of the 3x3 window's top-left position of the lane's A row
+    int base[TS];                   // cell offset (in halves) of the top-left position of the 3x3 window of the lane's position
 #pragma unroll
     for (int s = 0; s < TS; s++) {
-        int T = mq + MSPLIT * s; if (T >= NT) T = NT - 1;
-        int p = 16 * T + (lane & 15);
-        base[s] = ((p / 10) * PW + (p % 10)) * 8;
+        int T = mq + 2 * s; if (T >= NT) T = NT - 1;
+        const int p = 16 * T + pn;
+        base[s] = ((p / 10) * SPW + (p % 10)) * 8;
     }
 
+    // stem (one input channel): im2col GEMM on the fp32 matrix instruction as in k_trunk16s -- A = w[channel lane & 15 of the
+    // group][tap 4 st + g], B = the board value under that tap at the lane's position
     f32x4 x[TS];
     {
-        float w1[STEM];
+        float wA[STEM_STEPS];
+        int toff[STEM_STEPS];
 #pragma unroll
-        for (int i = 0; i < STEM; i++) w1[i] = wts[ch * STEM + i];
-        const float b0 = POST ? wts[FF * STEM + ch] : 0.f;
+        for (int st = 0; st < STEM_STEPS; st++) {
+            const int t = 4 * st + g, tc = t < STEM ? t : STEM - 1;
+            wA[st] = t < STEM ? wts[(cgroup * 16 + pn) * STEM + tc] : 0.f;
+            toff[st] = POST ? (tc / 3 + 1) * BW + (tc % 3) + 1 : (tc / 5) * BW + (tc % 5);
+        }
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f};
+        if (POST) b0 = *reinterpret_cast<const f32x4 *>(wts + FF * STEM + ch4);
 #pragma unroll
         for (int s = 0; s < TS; s++) {
-            int T = mq + MSPLIT * s; if (T >= NT) T = NT - 1;
+            int T = mq + 2 * s; if (T >= NT) T = NT - 1;
+            const int p = 16 * T + pn, pb = (p / 10) * BW + (p % 10);
+            f32x4 c = b0;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                int p = 16 * T + 4 * g + r, py = p / 10, px = p % 10;
-                float a = b0;
-                if (POST) {
-#pragma unroll
-                    for (int k = 0; k < 9; k++) a = fmaf(w1[k], brd[(py + 1 + k / 3) * BW + px + 1 + (k % 3)], a);
-                    a = fmaxf(a, 0.f);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 25; k++) a = fmaf(w1[k], brd[(py + k / 5) * BW + px + (k % 5)], a);
-                }
-                x[s][r] = a;
-            }
+            for (int st = 0; st < STEM_STEPS; st++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[st], brd[pb + toff[st]], c, 0, 0, 0);
+            x[s] = POST ? relu4(c) : c;
         }
     }
 
-    // this lane's output channel: oct-plane ch / 8, sub-channel ch % 8; its A rows: plane 4 kg + g
-    _Float16 *ownh = hiP + (2 * ntile + (co >> 3)) * W::PLANEH + (co & 7), *ownl = ownh + W::OCT * W::PLANEH;
+    // the lane's four channels live in oct-plane ch4 / 8 at sub-channel ch4 % 8 (= 0 or 4); its fragments: plane 4 kg + g
+    _Float16 *ownh = hiP + (2 * cgroup + (g >> 1)) * W::PLANEH + (SPW + 1) * 8 + 4 * (g & 1), *ownl = ownh + W::LO;
     const _Float16 *hiL = hiP + g * W::PLANEH, *loL = loP + g * W::PLANEH;
     const float *wb = wts + FF * STEM + (POST ? FF : 0);
-    f32x4 am[TS], ac[TS];
-    for (int layer = 0; layer < 2 * n_blocks; layer++) {
-        const bool first = !(layer & 1);
-        float sc = 1.f, sh = 0.f, bias = 0.f;
+    f32x4 am[TS];
+#ifdef TRL_PROFILE
+    unsigned long long tprof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    TPROF_T(tp_begin);
+    for (int blk = 0; blk < n_blocks; blk++)
+#pragma unroll
+    for (int half = 0; half < 2; half++) {            // the two convs of a block are separate code: nothing is selected at run time
+        TPROF_T(tp0);
+        const bool first = half == 0;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, bias = sh;
         const float *wq;
         if (POST) {                                    // block: b1[F] W1 b2[F] W2
-            bias = first ? wb[ch] : wb[FF + W::CONVW + ch];
+            bias = *reinterpret_cast<const f32x4 *>(first ? wb + ch4 : wb + FF + W::CONVW + ch4);
             wq = wb + (first ? FF : 2 * FF + W::CONVW);
         } else {                                       // block: s1[F] t1[F] Wa ba[F] Wb
-            if (first) { sc = wb[ch]; sh = wb[FF + ch]; bias = wb[2 * FF + W::CONVW + ch]; }
+#if TRL_EXP != 4
+            if (first) {
+                sc = *reinterpret_cast<const f32x4 *>(wb + ch4); sh = *reinterpret_cast<const f32x4 *>(wb + FF + ch4);
+                bias = *reinterpret_cast<const f32x4 *>(wb + 2 * FF + W::CONVW + ch4);
+            }
+#endif
             wq = wb + (first ? 2 * FF : 3 * FF + W::CONVW);
         }
-        const uint4 *wq4 = reinterpret_cast<const uint4 *>(wq) + ntile * 64 + lane;
+        const uint4 *wq4 = reinterpret_cast<const uint4 *>(wq) + cgroup * 64 + lane;
         const f16x8 wh = __builtin_bit_cast(f16x8, wq4[0]), wl = __builtin_bit_cast(f16x8, wq4[NN * 64]);
         // conv input -> planes (own positions), split: the block input (pre-activation: through bn1 + relu) for the first
         // conv, relu(previous conv) for the second
 #pragma unroll
-        for (int s = 0; s < TS; s++) {
-            int T = mq + MSPLIT * s;
-            if (T < NT) {
-                const uint2 o = otab[4 * T + g];
-                const unsigned off[4] = {o.x & 0xffffu, o.x >> 16, o.y & 0xffffu, o.y >> 16};
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float v = fmaxf(first ? (POST ? x[s][r] : fmaf(x[s][r], sc, sh)) : am[s][r], 0.f);
-                    const _Float16 h = (_Float16)v;
-                    ownh[off[r]] = h;
-                    ownl[off[r]] = (_Float16)((v - (float)h) * SPLIT);
-                }
+        for (int s = 0; s < (TRL_EXP == 3 ? 1 : TS); s++) {
+            if (s < 12 || mq == 0) {                   // (tile 25 does not exist)
+                const f32x4 v = relu4(first ? (POST ? x[s] : x[s] * sc + sh) : am[s]);
+                store_split4(ownh, ownl, base[s], v);
             }
         }
+        TPROF_T(tp1);
         __syncthreads();
+        TPROF_T(tp2);
 #pragma unroll
-        for (int s = 0; s < TS; s++) { am[s] = f32x4{bias, bias, bias, bias}; ac[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        if constexpr (MS == 1) conv_wide_s<FF>(hiL, loL, wq4, wh, wl, base, am, ac);
-        else {
-            if (mq == 0) conv_wide_s2<FF, 13>(hiL, loL, wq4, wh, wl, base, am, ac);
-            else conv_wide_s2<FF, 12>(hiL, loL, wq4, wh, wl, base, am, ac);
-        }
+        for (int s = 0; s < TS; s++) am[s] = bias * SPLIT;
+        if (mq == 0) conv_wide_s<FF, 13>(hiL, loL, wq4, wh, wl, base, am);
+        else conv_wide_s<FF, 12>(hiL, loL, wq4, wh, wl, base, am);
 #pragma unroll
-        for (int s = 0; s < TS; s++) am[s] += ac[s] * INV_SPLIT;
+        for (int s = 0; s < TS; s++) am[s] *= INV_SPLIT;
+        TPROF_T(tp3);
         if (!first) {
 #pragma unroll
             for (int s = 0; s < TS; s++) {
                 x[s] += am[s];
-                if (POST) { x[s][0] = fmaxf(x[s][0], 0.f); x[s][1] = fmaxf(x[s][1], 0.f); x[s][2] = fmaxf(x[s][2], 0.f); x[s][3] = fmaxf(x[s][3], 0.f); }
+                if (POST) x[s] = relu4(x[s]);
             }
             wb += POST ? 2 * FF + 2 * W::CONVW : 3 * FF + 2 * W::CONVW;
         }
+        TPROF_T(tp4);
         __syncthreads();                              // every wave has read its inputs: the planes can be overwritten
+        TPROF_T(tp5);
+        TPROF_ADD(0, tp0, tp1); TPROF_ADD(1, tp1, tp2); TPROF_ADD(2, tp2, tp3); TPROF_ADD(3, tp3, tp4); TPROF_ADD(4, tp4, tp5);
     }
+#ifdef TRL_PROFILE
+    {
+        TPROF_T(tp_end);
+        tprof[8] = tp_end - tp_begin;
+        if ((blockIdx.x == 0 || blockIdx.x == 300) && lane == 0 && wave < 8)
+            for (int i = 0; i < 10; i++) g_tprof[((blockIdx.x ? 1 : 0) * 8 + wave) * 10 + i] = tprof[i];
+    }
+#endif
 
     float *part = lds;                                 // [kout][NN][400] partial sums (the planes are dead now)
     if (POST) {
         for (int k = 0; k < kout; k++) {               // tail: kout 1x1 projections of the feature map, raw
-            const float wk = wb[k * FF + ch];
+            const f32x4 wk = *reinterpret_cast<const f32x4 *>(wb + k * FF + ch4);
 #pragma unroll
             for (int sidx = 0; sidx < TS; sidx++) {
-                int T = mq + MSPLIT * sidx;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    float v = x[sidx][r] * wk;
-                    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                    if (co == 0 && T < NT) part[(k * NN + ntile) * 400 + 16 * T + 4 * g + r] = v;
-                }
+                const int T = mq + 2 * sidx;
+                float v = x[sidx][0] * wk[0];
+                v = fmaf(x[sidx][1], wk[1], v); v = fmaf(x[sidx][2], wk[2], v); v = fmaf(x[sidx][3], wk[3], v);
+                v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+                if (g == 0 && T < NT) part[(k * NN + cgroup) * 400 + 16 * T + pn] = v;
             }
         }
         __syncthreads();
@@ -1100,17 +1097,18 @@ __global__ __launch_bounds__((WideS<FF, MS>::THREADS), MS) void k_trunk_wide_s(c
             out[(board * kout + k) * 400 + pos] = v;
         }
     } else {
-        // tail: relu(bn(x)) -> 1x1 conv over the FF channels (16 lanes x NN waves) -> folded bn -> relu
-        const float s = wb[ch], t = wb[FF + ch], wk = wb[2 * FF + ch], bk = wb[3 * FF];
+        // tail: relu(bn(x)) -> 1x1 conv over the FF channels (4 in the lane, 4 lane groups, NN waves) -> folded bn -> relu
+        const f32x4 s = *reinterpret_cast<const f32x4 *>(wb + ch4), t = *reinterpret_cast<const f32x4 *>(wb + FF + ch4);
+        const f32x4 wk = *reinterpret_cast<const f32x4 *>(wb + 2 * FF + ch4);
+        const float bk = wb[3 * FF];
 #pragma unroll
         for (int sidx = 0; sidx < TS; sidx++) {
-            int T = mq + MSPLIT * sidx;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float v = fmaxf(fmaf(x[sidx][r], s, t), 0.f) * wk;
-                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-                if (co == 0 && T < NT) part[ntile * 400 + 16 * T + 4 * g + r] = v;
-            }
+            const int T = mq + 2 * sidx;
+            const f32x4 y = relu4(x[sidx] * s + t);
+            float v = y[0] * wk[0];
+            v = fmaf(y[1], wk[1], v); v = fmaf(y[2], wk[2], v); v = fmaf(y[3], wk[3], v);
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (g == 0 && T < NT) part[cgroup * 400 + 16 * T + pn] = v;
         }
         __syncthreads();
         for (int i = tid; i < 400; i += THREADS) {
@@ -1190,18 +1188,12 @@ int trl_trunk_wide_split(const float *dev_boards, int n_boards, const float *dev
     if (!dev_boards || !dev_packed || !dev_out || n_boards <= 0 || n_blocks < 0 || (resnet && (kout < 1 || kout > 8)))
         return fail(TRL_E_INVALID, "trl_trunk_wide_split: %s", "bad argument");
     hipStream_t st = (hipStream_t)stream;
-    static const int ms = getenv("TRL_WIDE_MS") ? atoi(getenv("TRL_WIDE_MS")) : 2;      // probe knob: waves per N-tile
     if (filters != 32 && filters != 64)
         return fail(TRL_E_INVALID, "trl_trunk_wide_split: %s", "the split wide tower exists for 32 and 64 filters");
-#define TRL_LAUNCH_WS(FF_, POST_, MS_) hipLaunchKernelGGL((k_trunk_wide_s<FF_, POST_, MS_>), dim3(n_boards), dim3(WideS<FF_, MS_>::THREADS), \
-                                                          0, st, dev_boards, dev_packed, n_blocks, dev_out, dev_need, resnet ? kout : 1)
-    if (ms == 1) {
-        if (filters == 64) { if (resnet) TRL_LAUNCH_WS(64, true, 1); else TRL_LAUNCH_WS(64, false, 1); }
-        else { if (resnet) TRL_LAUNCH_WS(32, true, 1); else TRL_LAUNCH_WS(32, false, 1); }
-    } else {
-        if (filters == 64) { if (resnet) TRL_LAUNCH_WS(64, true, 2); else TRL_LAUNCH_WS(64, false, 2); }
-        else { if (resnet) TRL_LAUNCH_WS(32, true, 2); else TRL_LAUNCH_WS(32, false, 2); }
-    }
+#define TRL_LAUNCH_WS(FF_, POST_) hipLaunchKernelGGL((k_trunk_wide_s<FF_, POST_>), dim3(n_boards), dim3(WideS<FF_>::THREADS), \
+                                                     0, st, dev_boards, dev_packed, n_blocks, dev_out, dev_need, resnet ? kout : 1)
+    if (filters == 64) { if (resnet) TRL_LAUNCH_WS(64, true); else TRL_LAUNCH_WS(64, false); }
+    else { if (resnet) TRL_LAUNCH_WS(32, true); else TRL_LAUNCH_WS(32, false); }
 #undef TRL_LAUNCH_WS
     HIPCHK(hipGetLastError());
     return TRL_OK;

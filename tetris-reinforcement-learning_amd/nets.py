@@ -94,14 +94,18 @@ def _pack_conv3x3_split(w):
 
 
 def _pack_conv3x3_split_wide(w, f):
-    """w [f out, f in, 3, 3] (f = 32 or 64) -> the B operands of k_trunk_wide_s:
-    [K-step = kg * 9 + tap][hi | lo][N-tile][lane][8 halves]; lane (n = lane % 16, g = lane // 16) of N-tile nt holds
+    """w [f out, f in, 3, 3] (f = 32 or 64) -> the weight operands of k_trunk_wide_s:
+    [K-step = kg * 9 + tap][hi | lo][channel group][lane][8 halves]; lane (n = lane % 16, g = lane // 16) of group nt holds
     W[16 nt + n][32 kg + 8 g + j][tap]; hi = f16(w), lo = f16((w - hi) * 2^11).  float32 words (bit patterns)."""
     dev = w.device
     nn_, kgs = f // 16, f // 32
     lane = torch.arange(64, device=dev)
     n, g = lane & 15, lane >> 4
     w9 = w.reshape(f, f, 9).to(torch.float32)
+    if not bool((w9.abs() < 31.0).all()):
+        # the kernel forms 2^11 * hi in f16 (one accumulator for the product and its corrections): |w| must stay below 32
+        raise ValueError("split wide tower: a folded conv weight of magnitude >= 31 does not fit the kernel's scaled f16 operand; "
+                         "set TRL_TOWER=fp32 for this network")
     v = torch.empty((kgs, 9, nn_, 64, 8), dtype=torch.float32, device=dev)
     for kg in range(kgs):
         for nt in range(nn_):
