@@ -11,6 +11,7 @@
 template <int KIND>
 __global__ __launch_bounds__(256) void k(unsigned *out, int iters) {
     unsigned a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    unsigned s0 = blockIdx.x, s1 = s0 + 1, s2 = s0 + 2, s3 = s0 + 3, s4 = s0 + 4, s5 = s0 + 5, s6 = s0 + 6, s7 = s0 + 7;
     float f0 = a0, f1 = a1, f2 = a2, f3 = a3, f4 = a4, f5 = a5, f6 = a6, f7 = a7;
     for (int i = 0; i < iters; i++) {
         if (KIND == 0) { REP8(asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8\n" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(i));) }
@@ -31,7 +32,13 @@ __global__ __launch_bounds__(256) void k(unsigned *out, int iters) {
         else if (KIND == 15) { REP8(asm volatile("v_bcnt_u32_b32 %0, %0, %8\n v_bcnt_u32_b32 %1, %1, %8\n v_bcnt_u32_b32 %2, %2, %8\n v_bcnt_u32_b32 %3, %3, %8\n v_bcnt_u32_b32 %4, %4, %8\n v_bcnt_u32_b32 %5, %5, %8\n v_bcnt_u32_b32 %6, %6, %8\n v_bcnt_u32_b32 %7, %7, %8\n" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(i));) }
         else if (KIND == 16) { REP8(asm volatile("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8\n" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(i));) }
         else if (KIND == 17) { REP8(asm volatile("v_mad_u32_u24 %0, %0, %8, %1\n v_mad_u32_u24 %1, %1, %8, %2\n v_mad_u32_u24 %2, %2, %8, %3\n v_mad_u32_u24 %3, %3, %8, %4\n v_mad_u32_u24 %4, %4, %8, %5\n v_mad_u32_u24 %5, %5, %8, %6\n v_mad_u32_u24 %6, %6, %8, %7\n v_mad_u32_u24 %7, %7, %8, %0\n" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(i));) }
+        else if (KIND == 18) { REP8(asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %2, %2, 1\n s_add_u32 %3, %3, 1\n s_add_u32 %4, %4, 1\n s_add_u32 %5, %5, 1\n s_add_u32 %6, %6, 1\n s_add_u32 %7, %7, 1\n" : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7) : : "scc");) }
+        else if (KIND == 19) { REP8(asm volatile("s_andn2_b32 %0, %0, %1\n s_brev_b32 %1, %1\n s_or_b32 %2, %2, %3\n s_lshr_b32 %3, %3, 1\n s_andn2_b32 %4, %4, %5\n s_brev_b32 %5, %5\n s_or_b32 %6, %6, %7\n s_lshr_b32 %7, %7, 1\n" : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7) : : "scc");) }
+        else if (KIND == 20) { REP8(asm volatile("v_add_u32 %0, %0, %16\n s_add_u32 %8, %8, 1\n v_add_u32 %1, %1, %16\n s_add_u32 %9, %9, 1\n v_add_u32 %2, %2, %16\n s_add_u32 %10, %10, 1\n v_add_u32 %3, %3, %16\n s_add_u32 %11, %11, 1\n v_add_u32 %4, %4, %16\n s_add_u32 %12, %12, 1\n v_add_u32 %5, %5, %16\n s_add_u32 %13, %13, 1\n v_add_u32 %6, %6, %16\n s_add_u32 %14, %14, 1\n v_add_u32 %7, %7, %16\n s_add_u32 %15, %15, 1\n" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7) : "v"(i) : "scc");) }
+        else if (KIND == 21) { REP8(asm volatile("v_readlane_b32 %8, %0, 3\n v_readlane_b32 %9, %1, 3\n v_readlane_b32 %10, %2, 3\n v_readlane_b32 %11, %3, 3\n v_readlane_b32 %12, %4, 3\n v_readlane_b32 %13, %5, 3\n v_readlane_b32 %14, %6, 3\n v_readlane_b32 %15, %7, 3\n" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7));) }
+        else if (KIND == 22) { REP8(asm volatile("v_writelane_b32 %0, %8, 3\n v_writelane_b32 %1, %9, 3\n v_writelane_b32 %2, %10, 3\n v_writelane_b32 %3, %11, 3\n v_writelane_b32 %4, %12, 3\n v_writelane_b32 %5, %13, 3\n v_writelane_b32 %6, %14, 3\n v_writelane_b32 %7, %15, 3\n" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3), "+s"(s4), "+s"(s5), "+s"(s6), "+s"(s7));) }
     }
+    a0 ^= s0 ^ s1 ^ s2 ^ s3 ^ s4 ^ s5 ^ s6 ^ s7;
     out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7 ^ (unsigned)(f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7);
 }
 
@@ -78,6 +85,11 @@ int main() {
     run<13>("v_cndmask_b32", p.multiProcessorCount, ghz, d);
     run<14>("cmp+cndmask", p.multiProcessorCount, ghz, d);
     run<15>("v_bcnt_u32_b32", p.multiProcessorCount, ghz, d);
+    run<18>("s_add_u32", p.multiProcessorCount, ghz, d);
+    run<19>("s_andn2/brev/or/lshr", p.multiProcessorCount, ghz, d);
+    run<20>("v_add + s_add pairs", p.multiProcessorCount, ghz, d);
+    run<21>("v_readlane_b32", p.multiProcessorCount, ghz, d);
+    run<22>("v_writelane_b32", p.multiProcessorCount, ghz, d);
     run<16>("v_mul_lo_u32", p.multiProcessorCount, ghz, d);
     run<17>("v_mad_u32_u24", p.multiProcessorCount, ghz, d);
     return 0;

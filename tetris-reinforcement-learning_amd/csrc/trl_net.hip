@@ -281,13 +281,25 @@ constexpr float SPLIT = 2048.f, INV_SPLIT = 1.f / 2048.f;
 
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
-// four values (the lane's four channels of one position) -> hi and lo halves, one 8-byte store each
+// four values (the lane's four channels of one position) -> hi and lo halves, one 8-byte store each.
+// lo = f16((v - hi) * 2^11) as ONE v_fma_mix per value: fma(hi, -2^11, 2^11 v) -- the f16 source is widened inside the
+// instruction, the sum is exact (|v - hi| <= 2^-11 |v|, so 2^11 (v - hi) has at most 13 significant bits) and the result is
+// rounded to f16 once, like the four instructions (widen, subtract, scale, narrow) it replaces
+// (the compiler widens and narrows around a packed fp32 fma instead, so the two instructions are written out)
+__device__ __forceinline__ unsigned lo_pair(unsigned hpair, float a2, float b2) {
+    unsigned d;
+    const float negs = -SPLIT;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hpair), "v"(negs), "v"(a2));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hpair), "v"(negs), "v"(b2));
+    return d;
+}
 __device__ __forceinline__ void store_split4(_Float16 *hi, _Float16 *lo, int idx, f32x4 v) {
     const f16x4 h = __builtin_convertvector(v, f16x4);                  // 2 x v_cvt_pk_f16_f32 (round to nearest even)
-    const f32x4 back = __builtin_convertvector(h, f32x4);
-    const f16x4 l = __builtin_convertvector((v - back) * SPLIT, f16x4);
-    *reinterpret_cast<f16x4 *>(hi + idx) = h;
-    *reinterpret_cast<f16x4 *>(lo + idx) = l;
+    const f32x4 v2 = v * SPLIT;
+    const uint2 hp = __builtin_bit_cast(uint2, h);
+    const uint2 lp = make_uint2(lo_pair(hp.x, v2[0], v2[1]), lo_pair(hp.y, v2[2], v2[3]));
+    *reinterpret_cast<uint2 *>(hi + idx) = hp;
+    *reinterpret_cast<uint2 *>(lo + idx) = lp;
 }
 
 // B operand of one conv: 10 coalesced 16-byte loads per lane.  Issued BEFORE the activation writes and the barrier that
@@ -480,7 +492,7 @@ __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *_
 #pragma unroll
         for (int s = 0; s < 7; s++) {                               // H1 = relu(bn1(x)), split, own positions
             if (s < 6 || wave == 0) {
-                f32x4 v = x[s] * s1 + t1;
+                f32x4 v = __builtin_elementwise_fma(x[s], s1, t1);
                 v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
                 store_split4(hiP, loP, wofs[s], v);
             }
@@ -1039,7 +1051,7 @@ __global__ __launch_bounds__((WideS<FF>::THREADS), 2) void k_trunk_wide_s(const 
 #pragma unroll
         for (int s = 0; s < (TRL_EXP == 3 ? 1 : TS); s++) {
             if (s < 12 || mq == 0) {                   // (tile 25 does not exist)
-                const f32x4 v = relu4(first ? (POST ? x[s] : x[s] * sc + sh) : am[s]);
+                const f32x4 v = relu4(first ? (POST ? x[s] : __builtin_elementwise_fma(x[s], sc, sh)) : am[s]);
                 store_split4(ownh, ownl, base[s], v);
             }
         }
