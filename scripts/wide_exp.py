@@ -1,6 +1,10 @@
-"""timing experiments on the split wide tower: python scripts/wide_exp.py <library built with -DTRL_EXP=n> ...
-(TRL_EXP = 1: weights not re-read per K-step; 2: fragments not re-read; 3: one tile's split + write only -- results are
-wrong, the time shows what that ingredient costs)"""
+"""timing experiments on the split towers: python scripts/wide_exp.py [library built with -DTRL_EXP=n]
+k_trunk_wide_s: TRL_EXP = 1 weights not re-read per K-step; 2 fragments not re-read; 3 only one tile's split + write;
+4 no per-block parameter loads.  k_trunk16s: 5 no barriers; 6 fragments not re-read; 7 only one tile's split + write.
+Results are wrong; the time shows what that ingredient costs -- with care: a variant that leaves the planes zero also lets
+the chip clock higher (3 and 7 overstate the cost of the write phase for that reason).  Build:
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt
+-DTRL_EXP=n -o scripts/_prof/libexpn.so tetris-reinforcement-learning_amd/csrc/*.hip"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

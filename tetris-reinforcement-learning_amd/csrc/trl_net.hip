@@ -37,6 +37,11 @@ __device__ unsigned long long g_tprof[2 * 8 * 10];  // [workgroup 0 | 1500][wave
 #ifndef TRL_EXP
 #define TRL_EXP 0          // scripts/wide_exp.py: timing experiments that leave out one ingredient of a kernel (wrong results)
 #endif
+#if TRL_EXP == 5
+#define TRL_BLOCK_SYNC() do { } while (0)          // k_trunk16s without its barriers (timing experiment)
+#else
+#define TRL_BLOCK_SYNC() __syncthreads()
+#endif
 constexpr int F = 16;
 constexpr int PW = 12, PH = 42;                 // padded activation plane (1-cell zero border)
 constexpr int STRIDE = 16;                      // floats per position
@@ -302,124 +307,100 @@ __device__ __forceinline__ void store_split4(_Float16 *hi, _Float16 *lo, int idx
     *reinterpret_cast<uint2 *>(lo + idx) = lp;
 }
 
-// B operand of one conv: 10 coalesced 16-byte loads per lane.  Issued BEFORE the activation writes and the barrier that
-// precede the conv, so that their L2 latency is hidden behind them
-__device__ __forceinline__ void load_wsplit(const uint4 *wp, int lane, f16x8 (&wh)[5], f16x8 (&wl)[5]) {
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        const uint4 a = wp[(2 * c) * 64 + lane], b = wp[(2 * c + 1) * 64 + lane];
-        wh[c] = __builtin_bit_cast(f16x8, a);
-        wl[c] = __builtin_bit_cast(f16x8, b);
-    }
-}
-
-// am[s] = conv of the wave's tiles (slots 0..5 = tiles wave + 4 s; slot 6 = this wave's K-steps of tile 24), TRANSPOSED:
-// the weights are the matrix instruction's A operand and the activations its B operand, so a lane of the result holds
-// four consecutive output CHANNELS (4 g + r) of ONE position (tile position lane & 15) -- the split activations of a tile
-// are then two 8-byte LDS stores per lane instead of eight 2-byte ones, and the conversions pack in pairs.
-// The fragments of the next K-step are requested before the matrix instructions of the current one are issued (one wave
-// per SIMD when a board is alone on its CU: nothing else hides the LDS latency); the correction accumulators live only
-// for the pair of tiles in flight.
+// am[s] += 2^11 conv of the wave's tiles (slots 0..5 = tiles wave + 4 s; slot 6 = this wave's K-steps of tile 24),
+// TRANSPOSED: the weights are the matrix instruction's A operand and the activations its B operand, so a lane of the
+// result holds four consecutive output CHANNELS (4 g + r) of ONE position (tile position lane & 15) -- the split
+// activations of a tile are then two 8-byte LDS stores per lane instead of eight 2-byte ones.
+//   * K-step outermost: the weights of step c (hi and lo halves, 8 registers, + the hi half scaled by 2^11) serve all
+//     tiles of the wave and the next step's are already on their way from L2 (40 registers held a whole conv's weights
+//     before);
+//   * ONE accumulator per tile as in k_trunk_wide_s: bs hi_a, bh lo_a and bl hi_a all carry the factor 2^11;
+//   * the fragments of the next pair of tiles are requested before the matrix instructions of the current one are issued.
 // K-step c of a lane reads tap 2 c + (g >> 1), channels 8 (g & 1) .. + 7.  The tap's offset is A_c + (g >> 1) D_c positions
-// with A = {0, 2, SPW + 1, 2 SPW, 2 SPW + 2} and D = {1, SPW - 2, 1, 1, 0}: three lane-dependent bases per tile (D = 1, D = SPW - 2,
-// D = 0) and everything else is an immediate of the ds_read -- no address arithmetic between the matrix instructions
-// (one wave per SIMD issues a vector instruction every ~5 cycles; eight adds per K-step did not fit the MFMAs' gaps).
-struct SBase { const _Float16 *p1, *p10, *p0; };
-#ifndef TRL_PFD
-#define TRL_PFD 1
-#endif
-constexpr int PFD = TRL_PFD;       // K-steps between a fragment's ds_read and the matrix instructions that consume it
-template <int C> __device__ __forceinline__ const _Float16 *sb_ptr(const SBase &b) {
+// with A = {0, 2, SPW + 1, 2 SPW, 2 SPW + 2} and D = {1, SPW - 2, 1, 1, 0}: the lane-dependent part is one add, the rest an
+// immediate of the ds_read.
+struct SBase { const _Float16 *p0; };
+template <int C> __device__ __forceinline__ const _Float16 *sb_ptr(const SBase &b, int d1, int d10) {
     constexpr int A[5] = {0, 2, SPW + 1, 2 * SPW, 2 * SPW + 2};
-    return (C == 1 ? b.p10 : (C == 4 ? b.p0 : b.p1)) + A[C] * HST;
+    return (C == 1 ? b.p0 + d10 : (C == 4 ? b.p0 : b.p0 + d1)) + A[C] * HST;
 }
-template <int C> __device__ __forceinline__ void sb_load(const SBase &b, f16x8 &h, f16x8 &l) {
-    const _Float16 *p = sb_ptr<C>(b);
+template <int C> __device__ __forceinline__ void sb_load(const SBase &b, int d1, int d10, f16x8 &h, f16x8 &l) {
+    const _Float16 *p = sb_ptr<C>(b, d1, d10);
     h = *reinterpret_cast<const f16x8 *>(p);
     l = *reinterpret_cast<const f16x8 *>(p + LO_OFS);
 }
 
-template <bool INIT_BIAS, bool ILV, int I>
-__device__ __forceinline__ void conv_step(const SBase (&sb)[7], const f16x8 (&wh)[5], const f16x8 (&wl)[5], f32x4 bias,
-                                          f16x8 (&h0)[PFD + 1], f16x8 (&h1)[PFD + 1], f16x8 (&l0)[PFD + 1], f16x8 (&l1)[PFD + 1],
-                                          f32x4 &m0, f32x4 &m1, f32x4 &c0, f32x4 &c1, f32x4 (&am)[7]) {
-    constexpr int s = 2 * (I / 5), c = I % 5, cur = I % (PFD + 1);
-    if (c == 0) {
-        m0 = INIT_BIAS ? bias : f32x4{0.f, 0.f, 0.f, 0.f}; m1 = m0;
-        c0 = f32x4{0.f, 0.f, 0.f, 0.f}; c1 = c0;
+struct SW { f16x8 bs, bh, bl, nh, nl; };          // weights of the K-step in progress (bs = 2^11 bh) and of the next one
+
+// step I = 3 c + pair: tiles 2 pair, 2 pair + 1 on K-step c
+template <bool ILV, int I>
+__device__ __forceinline__ void conv_step(const SBase (&sb)[7], int d1, int d10, const uint4 *wp, SW &w, int wave,
+                                          f16x8 (&h0)[2], f16x8 (&h1)[2], f16x8 (&l0)[2], f16x8 (&l1)[2], f32x4 (&am)[7]) {
+    constexpr int c = I / 3, s = 2 * (I % 3), cur = I & 1, nxt = cur ^ 1;
+    if constexpr (I % 3 == 0) {
+        w.bh = w.nh; w.bl = w.nl; w.bs = w.bh * (_Float16)SPLIT;
+        if constexpr (c + 1 < 5) {
+            w.nh = __builtin_bit_cast(f16x8, wp[(2 * c + 2) * 64]);
+            w.nl = __builtin_bit_cast(f16x8, wp[(2 * c + 3) * 64]);
+        }
     }
-    // one fragment request in the shadow of each of the first four matrix instructions: four ds_read_b128 issued in a row
-    // held the wave's issue for ~25 cycles per K-step (scripts/mfma16_pattern.hip: 126 -> 101 cycles per step, one wave per SIMD)
-    // (ILV: the variant for one board per CU; with two waves per SIMD the other wave's matrix instructions cover the
-    // issue of a group of four reads, and grouped requests measured 5 % faster at 1024+ boards)
-    constexpr bool LD = I + PFD < 15;
-    constexpr int sn = LD ? 2 * ((I + PFD) / 5) : 0, cn = LD ? (I + PFD) % 5 : 0, nxt = (I + PFD) % (PFD + 1);
+    // (ILV: one fragment request in the shadow of each of the first four matrix instructions -- the variant for one board
+    // per CU, where four ds_read_b128 issued in a row held the wave's issue for ~25 cycles per step,
+    // scripts/mfma16_pattern.hip; with several waves per SIMD the others cover a group of four reads)
+    constexpr bool LD = I + 1 < 15 && TRL_EXP != 6;
+    constexpr int sn = LD ? 2 * ((I + 1) % 3) : 0, cn = LD ? (I + 1) / 3 : 0;
     if constexpr (LD && !ILV) {
-        sb_load<cn>(sb[sn], h0[nxt], l0[nxt]);
-        sb_load<cn>(sb[sn + 1], h1[nxt], l1[nxt]);
+        sb_load<cn>(sb[sn], d1, d10, h0[nxt], l0[nxt]);
+        sb_load<cn>(sb[sn + 1], d1, d10, h1[nxt], l1[nxt]);
     }
     __builtin_amdgcn_sched_barrier(0);
-    m0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], h0[cur], m0, 0, 0, 0);
+    am[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.bs, h0[cur], am[s], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (LD && ILV) h0[nxt] = *reinterpret_cast<const f16x8 *>(sb_ptr<cn>(sb[sn]));
+    if constexpr (LD && ILV) h0[nxt] = *reinterpret_cast<const f16x8 *>(sb_ptr<cn>(sb[sn], d1, d10));
     __builtin_amdgcn_sched_barrier(0);
-    m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], h1[cur], m1, 0, 0, 0);
+    am[s + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.bs, h1[cur], am[s + 1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (LD && ILV) h1[nxt] = *reinterpret_cast<const f16x8 *>(sb_ptr<cn>(sb[sn + 1]));
+    if constexpr (LD && ILV) h1[nxt] = *reinterpret_cast<const f16x8 *>(sb_ptr<cn>(sb[sn + 1], d1, d10));
     __builtin_amdgcn_sched_barrier(0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], l0[cur], c0, 0, 0, 0);
+    am[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.bh, l0[cur], am[s], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (LD && ILV) l0[nxt] = *reinterpret_cast<const f16x8 *>(sb_ptr<cn>(sb[sn]) + LO_OFS);
+    if constexpr (LD && ILV) l0[nxt] = *reinterpret_cast<const f16x8 *>(sb_ptr<cn>(sb[sn], d1, d10) + LO_OFS);
     __builtin_amdgcn_sched_barrier(0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], l1[cur], c1, 0, 0, 0);
+    am[s + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.bh, l1[cur], am[s + 1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (LD && ILV) l1[nxt] = *reinterpret_cast<const f16x8 *>(sb_ptr<cn>(sb[sn + 1]) + LO_OFS);
+    if constexpr (LD && ILV) l1[nxt] = *reinterpret_cast<const f16x8 *>(sb_ptr<cn>(sb[sn + 1], d1, d10) + LO_OFS);
     __builtin_amdgcn_sched_barrier(0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c], h0[cur], c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c], h1[cur], c1, 0, 0, 0);
+    am[s] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.bl, h0[cur], am[s], 0, 0, 0);
+    am[s + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.bl, h1[cur], am[s + 1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (c == 4) {
-        am[s] = m0 + c0 * INV_SPLIT;
-        am[s + 1] = m1 + c1 * INV_SPLIT;
+    if constexpr (I % 3 == 2) {
+        // tile 24 (25 tiles do not divide by 4 waves): its 5 K-steps are shared out 2 / 1 / 1 / 1 and summed through LDS
+        if ((c < 2 ? 0 : c - 1) == wave) {
+            f16x8 h, l;
+            sb_load<c>(sb[6], d1, d10, h, l);
+            am[6] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.bs, h, am[6], 0, 0, 0);
+            am[6] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.bh, l, am[6], 0, 0, 0);
+            am[6] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.bl, h, am[6], 0, 0, 0);
+        }
     }
-    if constexpr (I + 1 < 15) conv_step<INIT_BIAS, ILV, I + 1>(sb, wh, wl, bias, h0, h1, l0, l1, m0, m1, c0, c1, am);
+    if constexpr (I + 1 < 15) conv_step<ILV, I + 1>(sb, d1, d10, wp, w, wave, h0, h1, l0, l1, am);
 }
 
-template <int C> __device__ __forceinline__ void tile24_step(const SBase &b, const f16x8 (&wh)[5], const f16x8 (&wl)[5], int wave,
-                                                             f32x4 &m, f32x4 &cc) {
-    if ((C < 2 ? 0 : C - 1) == wave) {
-        f16x8 h, l;
-        sb_load<C>(b, h, l);
-        m = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[C], h, m, 0, 0, 0);
-        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[C], l, cc, 0, 0, 0);
-        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[C], h, cc, 0, 0, 0);
-    }
-    if constexpr (C + 1 < 5) tile24_step<C + 1>(b, wh, wl, wave, m, cc);
-}
-
-// am[s] = conv of the wave's tiles (slots 0..5 = tiles wave + 4 s; slot 6 = this wave's K-steps of tile 24), TRANSPOSED:
-// the weights are the matrix instruction's A operand and the activations its B operand, so a lane of the result holds
-// four consecutive output CHANNELS (4 g + r) of ONE position (tile position lane & 15) -- the split activations of a tile
-// are then two 8-byte LDS stores per lane instead of eight 2-byte ones, and the conversions pack in pairs.
-// The fragments of the next K-step are requested before the matrix instructions of the current one are issued (one wave
-// per SIMD when a board is alone on its CU: nothing else hides the LDS latency); the correction accumulators live only
-// for the pair of tiles in flight.
+// am[0..5] = bias + conv (bias only when INIT_BIAS), am[6] = the wave's share of tile 24 (no bias).  wp = the conv's packed
+// weights + lane; w.nh / w.nl = K-step 0's weights, requested by the caller before the writes and the barrier that
+// precede the conv
 template <bool INIT_BIAS, bool ILV>
-__device__ __forceinline__ void conv3x3s(const SBase (&sb)[7], const f16x8 (&wh)[5], const f16x8 (&wl)[5], f32x4 bias, int wave,
+__device__ __forceinline__ void conv3x3s(const SBase (&sb)[7], int d1, int d10, const uint4 *wp, SW &w, f32x4 bias, int wave,
                                          f32x4 (&am)[7]) {
-    f16x8 h0[PFD + 1], h1[PFD + 1], l0[PFD + 1], l1[PFD + 1];
-    sb_load<0>(sb[0], h0[0], l0[0]);
-    sb_load<0>(sb[1], h1[0], l1[0]);
-    if constexpr (PFD == 2) {
-        sb_load<1>(sb[0], h0[1], l0[1]);
-        sb_load<1>(sb[1], h1[1], l1[1]);
-    }
-    f32x4 m0, m1, c0, c1;
-    conv_step<INIT_BIAS, ILV, 0>(sb, wh, wl, bias, h0, h1, l0, l1, m0, m1, c0, c1, am);
-    // tile 24 (25 tiles do not divide by 4 waves): its 5 K-steps are shared out 2 / 1 / 1 / 1 and summed through LDS
-    f32x4 m = {0.f, 0.f, 0.f, 0.f}, cc = m;
-    tile24_step<0>(sb[6], wh, wl, wave, m, cc);
-    am[6] = m + cc * INV_SPLIT;
+    f16x8 h0[2], h1[2], l0[2], l1[2];
+    sb_load<0>(sb[0], d1, d10, h0[0], l0[0]);
+    sb_load<0>(sb[1], d1, d10, h1[0], l1[0]);
+#pragma unroll
+    for (int s = 0; s < 6; s++) am[s] = INIT_BIAS ? bias * SPLIT : f32x4{0.f, 0.f, 0.f, 0.f};
+    am[6] = f32x4{0.f, 0.f, 0.f, 0.f};
+    conv_step<ILV, 0>(sb, d1, d10, wp, w, wave, h0, h1, l0, l1, am);
+#pragma unroll
+    for (int s = 0; s < 7; s++) am[s] *= INV_SPLIT;
 }
 
 template <int MINB, bool ILV>
@@ -442,17 +423,16 @@ __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *_
     for (int i = tid; i < 400; i += TRUNK_THREADS) brd[(i / 10 + 2) * BW + (i % 10) + 2] = boards[board * 400 + i];
     __syncthreads();
 
-    SBase sb[7];                    // the lane's position in tile s: bases of its 3x3 window in the hi plane (see SBase)
-    int wofs[7];                    // where the lane's four channels of that position go in the planes
+    SBase sb[7];                    // the lane's position in tile s: base of its 3x3 window in the hi plane (see SBase)
 #pragma unroll
     for (int s = 0; s < 7; s++) {
         const int T = (s < 6) ? wave + 4 * s : NT - 1;
         const int p = 16 * T + pn;
-        const _Float16 *b = hiP + ((p / 10) * SPW + (p % 10)) * HST + 8 * (g & 1);
-        sb[s].p0 = b; sb[s].p1 = b + (g >> 1) * HST; sb[s].p10 = b + (g >> 1) * (SPW - 2) * HST;
-        wofs[s] = ((p / 10 + 1) * SPW + (p % 10) + 1) * HST + 4 * g;
+        sb[s].p0 = hiP + ((p / 10) * SPW + (p % 10)) * HST + 8 * (g & 1);
     }
-
+    const int d1 = (g >> 1) * HST, d10 = (g >> 1) * (SPW - 2) * HST;
+    // where the lane's four channels of its position go in the planes: sb[s].p0 + WOFS (window centre, channels 4 g ..)
+    const int WOFS = (SPW + 1) * HST + 4 * g - 8 * (g & 1);
     // 5x5 stem, one input channel: im2col GEMM on the fp32 matrix instruction as in k_trunk16 (7 per tile, once), with the
     // operands swapped like the convs': A = w1[channel = lane & 15][tap 4 st + g], B = board value under that tap at the
     // lane's position
@@ -479,7 +459,7 @@ __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *_
 
     const float *wb = wts + 400;
     f32x4 am[7];
-    f16x8 wh[5], wl[5];
+    SW w;
 #ifdef TRL_PROFILE
     unsigned long long tprof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -488,25 +468,26 @@ __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *_
         TPROF_T(tp0);
         const f32x4 s1 = *reinterpret_cast<const f32x4 *>(wb + 4 * g), t1 = *reinterpret_cast<const f32x4 *>(wb + 16 + 4 * g);
         const f32x4 bias_a = *reinterpret_cast<const f32x4 *>(wb + 32 + WCONV_S + 4 * g);
-        load_wsplit(reinterpret_cast<const uint4 *>(wb + 32), lane, wh, wl);
+        const uint4 *wpa = reinterpret_cast<const uint4 *>(wb + 32) + lane, *wpb = reinterpret_cast<const uint4 *>(wb + 32 + WCONV_S + 16) + lane;
+        w.nh = __builtin_bit_cast(f16x8, wpa[0]); w.nl = __builtin_bit_cast(f16x8, wpa[64]);
 #pragma unroll
         for (int s = 0; s < 7; s++) {                               // H1 = relu(bn1(x)), split, own positions
-            if (s < 6 || wave == 0) {
+            if ((s < 6 || wave == 0) && (TRL_EXP != 7 || s == 0)) {
                 f32x4 v = __builtin_elementwise_fma(x[s], s1, t1);
                 v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                store_split4(hiP, loP, wofs[s], v);
+                store_split4(const_cast<_Float16 *>(sb[s].p0), const_cast<_Float16 *>(sb[s].p0) + LO_OFS, WOFS, v);
             }
         }
         TPROF_T(tp1);
-        __syncthreads();
+        TRL_BLOCK_SYNC();
         TPROF_T(tp2);
         __builtin_amdgcn_s_setprio(0);
-        conv3x3s<true, ILV>(sb, wh, wl, bias_a, wave, am);
+        conv3x3s<true, ILV>(sb, d1, d10, wpa, w, bias_a, wave, am);
         __builtin_amdgcn_s_setprio(3);
         *reinterpret_cast<f32x4 *>(part + wave * 256 + lane * 4) = am[6];
-        load_wsplit(reinterpret_cast<const uint4 *>(wb + 32 + WCONV_S + 16), lane, wh, wl);      // conv B's weights
+        w.nh = __builtin_bit_cast(f16x8, wpb[0]); w.nl = __builtin_bit_cast(f16x8, wpb[64]);      // conv b's first weights
         TPROF_T(tp3);
-        __syncthreads();                              // every wave has read its halo: the planes can be overwritten
+        TRL_BLOCK_SYNC();                              // every wave has read its halo: the planes can be overwritten
         TPROF_T(tp4);
         if (wave == 0) {
             f32x4 t = *reinterpret_cast<const f32x4 *>(part + lane * 4);
@@ -517,23 +498,23 @@ __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *_
         }
 #pragma unroll
         for (int s = 0; s < 7; s++) {
-            if (s < 6 || wave == 0) {
+            if ((s < 6 || wave == 0) && (TRL_EXP != 7 || s == 0)) {
                 f32x4 v = am[s];
                 v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                store_split4(hiP, loP, wofs[s], v);
+                store_split4(const_cast<_Float16 *>(sb[s].p0), const_cast<_Float16 *>(sb[s].p0) + LO_OFS, WOFS, v);
             }
         }
         TPROF_T(tp5);
-        __syncthreads();
+        TRL_BLOCK_SYNC();
         TPROF_T(tp6);
         __builtin_amdgcn_s_setprio(0);
-        conv3x3s<false, ILV>(sb, wh, wl, f32x4{0.f, 0.f, 0.f, 0.f}, wave, am);
+        conv3x3s<false, ILV>(sb, d1, d10, wpb, w, f32x4{0.f, 0.f, 0.f, 0.f}, wave, am);
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int s = 0; s < 6; s++) x[s] += am[s];
         *reinterpret_cast<f32x4 *>(part + wave * 256 + lane * 4) = am[6];
         TPROF_T(tp7);
-        __syncthreads();
+        TRL_BLOCK_SYNC();
         TPROF_T(tp8);
         TPROF_ADD(0, tp0, tp1); TPROF_ADD(1, tp1, tp2); TPROF_ADD(2, tp2, tp3); TPROF_ADD(3, tp3, tp4); TPROF_ADD(4, tp4, tp5);
         TPROF_ADD(5, tp5, tp6); TPROF_ADD(6, tp6, tp7); TPROF_ADD(7, tp7, tp8);
@@ -1161,7 +1142,8 @@ int trl_alphasame_trunk16_split(const float *dev_boards, int n_boards, const flo
     if (!dev_boards || !dev_packed || !dev_out || n_boards <= 0 || n_blocks < 0)
         return fail(TRL_E_INVALID, "trl_alphasame_trunk16_split: %s", "bad argument");
     // up to one board per CU the fragment reads are interleaved with the matrix instructions, beyond that grouped (see
-    // conv_step); TRL_SPLIT_ILV = 0 / 1 forces one form (probe knob)
+    // conv_step); TRL_SPLIT_ILV = 0 / 1 forces one form (probe knob).  Three boards per CU (168 registers, measured with
+    // the same kernel) ran at the speed of two: 768 boards 89 against 96 us, 1536 169 against 172.
     static const int force = getenv("TRL_SPLIT_ILV") ? atoi(getenv("TRL_SPLIT_ILV")) : -1;
     if (force < 0 ? n_boards <= 256 : force != 0)
         hipLaunchKernelGGL((k_trunk16s<2, true>), dim3(n_boards), dim3(TRUNK_THREADS), 0, (hipStream_t)stream, dev_boards,
