@@ -131,9 +131,15 @@ __device__ unsigned long long g_slot_t[2 * 16384];     // per slot: wall clock a
 //   launch against 40.7 here; profiles/r02/r02a_rollout_regime.txt, r02f_rollout_tail.txt).  What remains at 20 plies
 //   is the critical path of the most expensive games: even with the SIMD to itself a wave needs ~25 us for a ply.
 __global__ __launch_bounds__(BLOCK, 8) void k_rollout(trl_game_state *states, uint64_t seed, int n_plies, int max_plies,
-                                                   unsigned long long *steps_total, unsigned int *prog, int rankt) {
+                                                   unsigned long long *steps_total, unsigned int *prog, int rankt,
+                                                   unsigned long long *steps_next, unsigned int *prog_next) {
     __shared__ BlockShared sh;
     const int tid = threadIdx.x, game = blockIdx.x;
+    if (tid == 0) {                 // the next launch's counters (the other block: nobody reads it during this launch)
+        const int S = ((int)gridDim.x + 63) >> 6;
+        prog_next[(game % S) * 64 + game / S] = 0;
+        if (game == 0) *steps_next = 0;
+    }
 #ifdef TRL_SLOT_TIMES
     const unsigned long long t_begin = wall_clock64();
 #endif
@@ -230,10 +236,14 @@ int trl_engine_create(const trl_config *cfg, trl_engine **out) {
         HIPCHK(hipMalloc(&h->d_counts, n * sizeof(uint16_t)));
         HIPCHK(hipMalloc(&h->d_moves, n * TRL_MAX_LEGAL * sizeof(uint16_t)));
         HIPCHK(hipMalloc(&h->d_in_moves, n * sizeof(uint16_t)));
-        // one block, zeroed by one memset per rollout launch: [0] env-steps of the launch (+ 8 bytes of padding), then the
-        // plies played in the launch per slot (rollout pacing)
-        HIPCHK(hipMalloc(&h->d_steps, 16 + (n + 63) / 64 * 64 * sizeof(unsigned int)));
+        // two blocks of [env-steps of the launch (+ 8 bytes of padding)][plies played in the launch per slot (rollout
+        // pacing)]: a rollout launch counts in one and zeroes the other for its successor -- no memset between launches
+        h->pp_stride = 16 + (n + 63) / 64 * 64 * sizeof(unsigned int);
+        HIPCHK(hipMalloc(&h->d_steps, 2 * h->pp_stride));
+        HIPCHK(hipMemset(h->d_steps, 0, 2 * h->pp_stride));
         h->d_prog = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(h->d_steps) + 16);
+        h->pp = 0;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h->h_steps), 64));
         HIPCHK(hipEventCreate(&h->ev0));
         HIPCHK(hipEventCreate(&h->ev1));
         return TRL_OK;
@@ -241,6 +251,7 @@ int trl_engine_create(const trl_config *cfg, trl_engine **out) {
     int rc = alloc();
     if (rc != TRL_OK) {                            // release what was allocated before the failure
         hipFree(h->d_states); hipFree(h->d_counts); hipFree(h->d_moves); hipFree(h->d_in_moves); hipFree(h->d_steps);
+        if (h->h_steps) hipHostFree(h->h_steps);
         if (h->ev0) hipEventDestroy(h->ev0);
         if (h->ev1) hipEventDestroy(h->ev1);
         if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -259,6 +270,7 @@ void trl_engine_destroy(trl_engine *h) {
     if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
     if (h->graph) hipGraphDestroy(h->graph);
     hipFree(h->d_states); hipFree(h->d_counts); hipFree(h->d_moves); hipFree(h->d_in_moves); hipFree(h->d_steps);
+    if (h->h_steps) hipHostFree(h->h_steps);
     hipEventDestroy(h->ev0); hipEventDestroy(h->ev1);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
@@ -403,24 +415,25 @@ int trl_env_rollout_random(trl_engine *h, int n_plies, int max_plies, uint64_t *
     if (!h || n_plies < 0 || max_plies <= 0) return fail(TRL_E_INVALID, "%s", "bad argument");
     if (!h->have_reset) return fail(TRL_E_STATE, "%s", "trl_env_rollout_random before trl_env_reset / trl_env_set_state");
     HIPCHK(hipSetDevice(h->cfg.device));
-    const size_t prog_bytes = ((size_t)h->cfg.n_games + 63) / 64 * 64 * sizeof(unsigned int);
     int pacing = h->cfg.n_games <= 16 * h->n_cu;                            // 16 workgroups of this kernel fit a CU
     int r3 = 4, r2 = 16, r1 = 40;                                           // ranks (of 64) that get priority 3 / 2 / 1
     if (const char *e = getenv("TRL_PACE")) pacing = atoi(e) != 0;          // probe knobs (scripts/rollout_tail_probe.py)
     if (const char *e = getenv("TRL_PACE_R")) sscanf(e, "%d,%d,%d", &r3, &r2, &r1);
     const int rankt = pacing ? ((r3 & 255) | ((r2 & 255) << 8) | ((r1 & 255) << 16)) : 0;
-    HIPCHK(hipMemsetAsync(h->d_steps, 0, 16 + (rankt ? prog_bytes : 0), h->stream));
+    char *blk = reinterpret_cast<char *>(h->d_steps) + (size_t)h->pp * h->pp_stride;
+    char *nxt = reinterpret_cast<char *>(h->d_steps) + (size_t)(h->pp ^ 1) * h->pp_stride;
+    h->pp ^= 1;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     hipLaunchKernelGGL(k_rollout, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->d_states, h->cfg.seed,
-                       n_plies, max_plies, h->d_steps, h->d_prog, rankt);
+                       n_plies, max_plies, reinterpret_cast<unsigned long long *>(blk), reinterpret_cast<unsigned int *>(blk + 16),
+                       rankt, reinterpret_cast<unsigned long long *>(nxt), reinterpret_cast<unsigned int *>(nxt + 16));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     if (steps_out) {
-        unsigned long long s = 0;
-        HIPCHK(hipMemcpyAsync(&s, h->d_steps, sizeof s, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipMemcpyAsync(h->h_steps, blk, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));   // pinned: no staging
         HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipEventElapsedTime(&h->last_ms, h->ev0, h->ev1));
-        *steps_out = s;
+        *steps_out = *h->h_steps;
     }
     return TRL_OK;
 }

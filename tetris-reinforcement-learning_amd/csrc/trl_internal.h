@@ -82,8 +82,11 @@ struct trl_engine {
     bool own_stream;
     trl_game_state *d_states;
     uint16_t *d_counts, *d_moves, *d_in_moves;
-    unsigned long long *d_steps;
+    unsigned long long *d_steps;   // two blocks of [step count, 16 bytes][plies per slot]: a launch uses one and zeroes the other
     unsigned int *d_prog;
+    size_t pp_stride;              // bytes per block
+    int pp;                        // block of the next launch
+    unsigned long long *h_steps;   // pinned host word the step count is copied to
     hipEvent_t ev0, ev1;
     bool have_reset;
     float last_ms;
