@@ -176,3 +176,22 @@ def test_default_size_nets_have_the_reference_key_layout(golden_dir):
         sd = net.state_dict()
         assert list(sd.keys()) == [str(k) for k in d["%s/keys" % tag]]
         assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in d["%s/shapes" % tag]]
+
+
+def test_split_pack_refuses_weights_out_of_range():
+    """the split towers scale the weights' hi half by 2^11 in f16: a folded weight of magnitude >= 31 cannot be packed for
+    them; prepare() then keeps the fp32 tower kernels for that network (a warning, not a different result)"""
+    import warnings
+    from tetris_rl_amd import nets
+    w = torch.zeros(16, 16, 3, 3)
+    w[3, 5, 1, 1] = 30.0
+    nets._pack_conv3x3_split(w)                                   # fits
+    w[3, 5, 1, 1] = -40.0
+    with pytest.raises(nets.SplitRangeError):
+        nets._pack_conv3x3_split(w)
+    with pytest.raises(nets.SplitRangeError):
+        nets._pack_conv3x3_split_wide(torch.full((32, 32, 3, 3), 64.0), 32)
+    with warnings.catch_warnings(record=True) as got:
+        warnings.simplefilter("always")
+        assert nets._split_or_none(lambda: nets._pack_conv3x3_split(w)) is None
+    assert got and "fp32 tower" in str(got[0].message)

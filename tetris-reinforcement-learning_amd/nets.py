@@ -71,6 +71,15 @@ def _pack_conv3x3(w, f):
 SPLIT_SCALE = 2048.0        # csrc/trl_net.hip k_trunk16s: a = hi + lo / 2^11
 
 
+class SplitRangeError(ValueError):
+    """a folded conv weight is too large for the split towers (they form 2^11 * hi in f16: |w| must stay below 32)"""
+
+
+def _check_split_range(w9):
+    if not bool((w9.abs() < 31.0).all()):
+        raise SplitRangeError("split tower: a folded conv weight of magnitude >= 31 does not fit the kernels' scaled f16 operand")
+
+
 def _pack_conv3x3_split(w):
     """w [16 out, 16 in, 3, 3] -> the B operands of v_mfma_f32_16x16x32_f16 for the split tower (k_trunk16s):
     [K-step c = 0..4][hi | lo][lane][8 halves]; lane (n = lane % 16, g = lane // 16) holds W[n][8 (g & 1) + j][tap] for
@@ -80,6 +89,7 @@ def _pack_conv3x3_split(w):
     lane = torch.arange(64, device=dev)
     n, g = lane & 15, lane >> 4
     w9 = w.reshape(16, 16, 9).to(torch.float32)
+    _check_split_range(w9)
     out = torch.zeros((5, 2, 64, 8), dtype=torch.float16, device=dev)
     for c in range(5):
         tap = 2 * c + (g >> 1)
@@ -102,10 +112,7 @@ def _pack_conv3x3_split_wide(w, f):
     lane = torch.arange(64, device=dev)
     n, g = lane & 15, lane >> 4
     w9 = w.reshape(f, f, 9).to(torch.float32)
-    if not bool((w9.abs() < 31.0).all()):
-        # the kernel forms 2^11 * hi in f16 (one accumulator for the product and its corrections): |w| must stay below 32
-        raise ValueError("split wide tower: a folded conv weight of magnitude >= 31 does not fit the kernel's scaled f16 operand; "
-                         "set TRL_TOWER=fp32 for this network")
+    _check_split_range(w9)
     v = torch.empty((kgs, 9, nn_, 64, 8), dtype=torch.float32, device=dev)
     for kg in range(kgs):
         for nt in range(nn_):
@@ -115,6 +122,17 @@ def _pack_conv3x3_split_wide(w, f):
     lo = ((v - hi.to(torch.float32)) * SPLIT_SCALE).to(torch.float16)
     out = torch.stack([hi, lo], dim=2)                    # [kg][tap][2][nt][lane][8]
     return out.reshape(-1).view(torch.float32)
+
+
+def _split_or_none(pack):
+    """the split towers' packed weights, or None (= the fp32-MFMA tower kernels run instead) when a weight is out of
+    their range -- said aloud: the two towers differ in speed, not in results"""
+    try:
+        return pack()
+    except SplitRangeError as e:
+        import warnings
+        warnings.warn("%s; using the fp32 tower kernels for this network" % e, RuntimeWarning, stacklevel=3)
+        return None
 
 
 class AlphaSame(nn.Module):
@@ -166,7 +184,7 @@ class AlphaSame(nn.Module):
         fd["packed_tower"] = self._pack_tower(fd) if (self.model_config.filters in self.HIP_TOWER_FILTERS and self.model_config.kernels == 1
                                               and self.conv1.weight.is_cuda) else None
         # the 16-filter tower on the f16 matrix rate with split operands (k_trunk16s): fp32 accuracy, see csrc/trl_net.hip
-        fd["packed_split"] = self._pack_tower_split(fd) if fd["packed_tower"] is not None else None
+        fd["packed_split"] = _split_or_none(lambda: self._pack_tower_split(fd)) if fd["packed_tower"] is not None else None
         self._folded = fd
         return self
 
@@ -442,11 +460,13 @@ class BaseResNet(nn.Module):
             # tail: the own_kernels rows of own_collapse, then the row of opp_collapse (kout = own_kernels + 1)
             parts += [fd["own"][0].reshape(-1), fd["opp"][0].reshape(-1), torch.zeros(4096, device=fd["own"][0].device)]
             fd["packed_tower"] = torch.cat([p.reshape(-1).to(torch.float32) for p in parts]).contiguous()
-            parts = [fd["stem"][0].reshape(-1), fd["stem"][1]]
-            for (w1, b1), (w2, b2) in fd["blocks"]:
-                parts += [b1, _pack_conv3x3_split_wide(w1, f), b2, _pack_conv3x3_split_wide(w2, f)]
-            parts += [fd["own"][0].reshape(-1), fd["opp"][0].reshape(-1), torch.zeros(4096, device=fd["own"][0].device)]
-            fd["packed_split"] = torch.cat([p.reshape(-1).to(torch.float32) for p in parts]).contiguous()
+            def pack_split():
+                parts = [fd["stem"][0].reshape(-1), fd["stem"][1]]
+                for (w1, b1), (w2, b2) in fd["blocks"]:
+                    parts += [b1, _pack_conv3x3_split_wide(w1, f), b2, _pack_conv3x3_split_wide(w2, f)]
+                parts += [fd["own"][0].reshape(-1), fd["opp"][0].reshape(-1), torch.zeros(4096, device=fd["own"][0].device)]
+                return torch.cat([p.reshape(-1).to(torch.float32) for p in parts]).contiguous()
+            fd["packed_split"] = _split_or_none(pack_split)
         self._folded = fd
         return self
 
