@@ -84,55 +84,83 @@ def forward_train(net, *features):
     raise TypeError("no training forward for %r" % type(net).__name__)
 
 
-# ---- ai.py:1139-1220 -------------------------------------------------------------------------------------------
+# ---- the training step (ai.py:1139-1220) -------------------------------------------------------------------------
+# Same arithmetic in the same order as the reference -- the tests compare losses and every updated weight with the
+# reference's own step -- organised as: columns -> batches (the reference's DataLoader, because its shuffling draws from
+# torch's global generator and the order of the batches is part of the result) -> objective terms -> running means.
+class _Columns:
+    """the 13 feature columns of a training set as tensors (board columns as float [n, 1, 40, 10])"""
+
+    def __init__(self, source):
+        if isinstance(source, tuple):                          # records.PackedSet.features(): arrays, no detour through lists
+            cols = [torch.from_numpy(np.ascontiguousarray(c)) for c in source]
+        else:                                                  # the reference's list of 13-field records
+            cols = [torch.tensor(list(c)) for c in zip(*source)]
+        self.tensors = [c.unsqueeze(1).to(torch.float) if (c.dim() == 3 and tuple(c.shape[1:]) == (ROWS, COLS)) else c for c in cols]
+
+    def batches(self, config):
+        return torch.utils.data.DataLoader(torch.utils.data.TensorDataset(*self.tensors), batch_size=config.batch_size,
+                                           shuffle=config.shuffle)
+
+
+class _Means:
+    """per-term sums over the optimiser steps of one call, reported as means"""
+
+    def __init__(self, names):
+        self.sums, self.steps = {n: 0.0 for n in names}, 0
+
+    def add(self, **terms):
+        for n, v in terms.items():
+            self.sums[n] += v.item()
+        self.steps += 1
+
+    def mean(self, name):
+        return self.sums[name] / max(self.steps, 1)
+
+
+def _objective(model, inputs, z, pi, aux_weight):
+    """(total, value term, policy term, aux term or None): MSE on the value, cross-entropy against the visit distribution,
+    MSE on the auxiliary head (holes / height of the own board, weighted) for the Aux nets"""
+    out = forward_train(model, *inputs)
+    value_term = F.mse_loss(out[0].reshape(-1), z)
+    policy_term = F.cross_entropy(out[1].reshape(-1, POLICY_SIZE), pi)
+    total = value_term + policy_term
+    aux_term = None
+    if len(out) > 2:
+        aux_term = F.mse_loss(out[2], compute_aux_targets(inputs[0]))
+        total = total + aux_weight * aux_term
+    return total, value_term, policy_term, aux_term
+
+
 def train_network_pytorch(config, model, set, data_number=None, device=None):
     """`set`: the reference's list of 13-field records, or the 13 feature arrays of records.PackedSet.features()
     (a tuple) -- the same tensors without the detour through nested Python lists"""
     device = device or next(model.parameters()).device
-    if isinstance(set, tuple):
-        features = [torch.from_numpy(np.ascontiguousarray(f)) for f in set]
-    else:
-        features = list(map(list, zip(*set)))
-    for i in range(len(features)):
-        if not isinstance(features[i], torch.Tensor):
-            features[i] = torch.tensor(features[i])
-        if features[i].dim() == 3 and features[i].shape[1] == ROWS and features[i].shape[2] == COLS:
-            features[i] = features[i].unsqueeze(dim=1).type(torch.float)
-    dataset = torch.utils.data.TensorDataset(*features)
-    loader = torch.utils.data.DataLoader(dataset, batch_size=config.batch_size, shuffle=config.shuffle)
-    loss_value, loss_policy, loss_aux = nn.MSELoss(), nn.CrossEntropyLoss(), nn.MSELoss()
+    columns = _Columns(set)
+    is_aux = isinstance(config.model_config, nets.AuxBaseResNetConfig)
+    aux_weight = config.model_config.aux_weight if is_aux else 0.0
     optimizer = torch.optim.AdamW(model.parameters(), lr=config.learning_rate, weight_decay=config.weight_decay)
-    has_aux = isinstance(config.model_config, nets.AuxBaseResNetConfig)
-    aux_weight = config.model_config.aux_weight if has_aux else 0.0
+    means = _Means(["loss", "value_loss", "policy_loss"] + (["aux_loss"] if is_aux else []))
     model.train()
-    total = v_sum = p_sum = a_sum = 0.0
-    batches = 0
     for _ in range(config.epochs):
-        for batch in loader:
-            batch = [t.to(device) for t in batch]
-            y_policy = batch.pop().reshape(-1, POLICY_SIZE)
-            y_value = batch.pop().type(torch.float)
-            out = forward_train(model, *batch)
-            pred_value, pred_policy = out[0].reshape(-1), out[1].reshape(-1, POLICY_SIZE)
-            l1, l2 = loss_value(pred_value, y_value), loss_policy(pred_policy, y_policy)
-            loss = l1 + l2
-            if has_aux:
-                l3 = loss_aux(out[2], compute_aux_targets(batch[0]))
-                loss = loss + aux_weight * l3
-                a_sum += l3.item()
-            loss.backward()
+        for batch in columns.batches(config):
+            *inputs, z, pi = (t.to(device) for t in batch)
+            total, value_term, policy_term, aux_term = _objective(model, inputs, z.to(torch.float), pi.reshape(-1, POLICY_SIZE), aux_weight)
+            total.backward()
             optimizer.step()
             optimizer.zero_grad()
-            v_sum += l1.item(); p_sum += l2.item(); total += loss.item()
-            batches += 1
+            terms = {"loss": total, "value_loss": value_term, "policy_loss": policy_term}
+            if is_aux:
+                terms["aux_loss"] = aux_term
+            means.add(**terms)
     model.eval()
     model._folded = None                      # the folded inference weights are stale now
-    nb = max(batches, 1)
     entry = {"model_version": config.model_version,
-             "data_number": data_number if data_number is not None else selfplay.highest_data_number(config),
-             "loss": total / nb, "value_loss": v_sum / nb, "policy_loss": p_sum / nb, "backend": "pytorch"}
-    if has_aux:
-        entry["aux_loss"] = a_sum / nb
+             "data_number": data_number if data_number is not None else selfplay.highest_data_number(config)}
+    entry.update({name: means.mean(name) for name in ("loss", "value_loss", "policy_loss")})
+    entry["backend"] = "pytorch"
+    if is_aux:
+        entry["aux_loss"] = means.mean("aux_loss")
     logs = selfplay.storage_root() / "logs"
     logs.mkdir(parents=True, exist_ok=True)
     with open(logs / "training_log.jsonl", "a") as f:
