@@ -342,9 +342,13 @@ int  trl_mcts_root_children(trl_engine *h, int32_t *counts, uint16_t *moves, int
  * Everything issued on the engine's stream between trl_graph_begin and trl_graph_end (trl_mcts_select*,
  * the tower, trl_mcts_expand* -- device pointers only, no host copies) is captured into one hipGraph;
  * trl_graph_launch replays it n_times on the same stream.  Replaces the reference's Python loop over
- * MAX_ITER iterations (ai.py:330-338) as the unit of host work.                                      */
+ * MAX_ITER iterations (ai.py:330-338) as the unit of host work.
+ * Optionally a second capture of the same calls issued `ticks` (>= 2) times in a row, ended by
+ * trl_graph_end_many (after trl_graph_end): trl_graph_launch then replays that graph n_times / ticks
+ * times and the single tick for the remainder -- the stream does not idle between the ticks of one graph. */
 int  trl_graph_begin(trl_engine *h);
 int  trl_graph_end(trl_engine *h);
+int  trl_graph_end_many(trl_engine *h, int ticks);
 int  trl_graph_launch(trl_engine *h, int n_times);
 
 /* ==== net: residual tower of AlphaSame on the device (architectures.py:27-57, 119-127) ===========

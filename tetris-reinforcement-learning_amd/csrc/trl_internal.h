@@ -94,6 +94,9 @@ struct trl_engine {
     int n_cu = 0;                          // compute units of the device (rollout pacing: are all slots resident?)
     hipGraph_t graph = nullptr;            // captured search tick (trl_graph_begin / _end / _launch)
     hipGraphExec_t graph_exec = nullptr;
+    hipGraph_t graph_many = nullptr;       // TRL_GRAPH_UNROLL copies of it in a chain: one launch, no gap between the ticks
+    hipGraphExec_t graph_many_exec = nullptr;
+    int graph_unroll = 1;
 };
 
 extern thread_local char trl_g_err[512];

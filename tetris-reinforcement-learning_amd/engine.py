@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "trl_env_legal_moves", "trl_env_legal_moves_algo", "trl_env_legal_dev", "trl_env_step", "trl_env_step_dev",
     "trl_env_rollout_random", "trl_last_kernel_ms",
     "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_expand_head", "trl_mcts_drain_records", "trl_mcts_drain_records_dev", "trl_mcts_get_stats",
-    "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16", "trl_alphasame_trunk16_need", "trl_alphasame_trunk16_split", "trl_trunk_wide_split", "trl_alphasame_trunk", "trl_resnet_trunk", "trl_graph_begin", "trl_graph_end", "trl_graph_launch",
+    "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16", "trl_alphasame_trunk16_need", "trl_alphasame_trunk16_split", "trl_trunk_wide_split", "trl_alphasame_trunk", "trl_resnet_trunk", "trl_graph_begin", "trl_graph_end", "trl_graph_end_many", "trl_graph_launch",
     "trl_mcts_select_need", "trl_mcts_fork_legal", "trl_mcts_expand_alphasame_masked", "trl_mcts_zcache", "trl_mcts_zcache_dim", "trl_mcts_expand_alphasame",
 ]
 
@@ -137,6 +137,7 @@ def load_library(path=None):
     L.trl_mcts_zcache_dim.argtypes = [C.c_void_p, C.c_int]
     L.trl_graph_begin.argtypes = [C.c_void_p]
     L.trl_graph_end.argtypes = [C.c_void_p]
+    L.trl_graph_end_many.argtypes = [C.c_void_p, C.c_int]
     L.trl_graph_launch.argtypes = [C.c_void_p, C.c_int]
     L.trl_mcts_expand_alphasame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(TrlAlphaSameHeads)]
     L.trl_mcts_expand_alphasame_masked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(TrlAlphaSameHeads),
@@ -275,6 +276,9 @@ class Engine:
 
     def graph_end(self):
         _check(self._L, self._L.trl_graph_end(self._h), "trl_graph_end")
+
+    def graph_end_many(self, ticks):
+        _check(self._L, self._L.trl_graph_end_many(self._h, int(ticks)), "trl_graph_end_many")
 
     def graph_launch(self, n=1):
         _check(self._L, self._L.trl_graph_launch(self._h, int(n)), "trl_graph_launch")

@@ -119,6 +119,9 @@ def derive_seed(base, *parts):
 
 
 # ---- the tick loop ----------------------------------------------------------------------------------------
+GRAPH_TICKS = int(os.environ.get("TRL_GRAPH_TICKS", "8"))      # ticks per launch of the long tick graph (1: single-tick graph only)
+
+
 class SelfPlay:
     """n_slots concurrent self-play games: Engine + net + HIP-graph tick."""
 
@@ -207,6 +210,11 @@ class SelfPlay:
                 self.engine.graph_begin()
                 self._tick_body()
                 self.engine.graph_end()
+                if GRAPH_TICKS > 1:                   # the same tick GRAPH_TICKS times in one graph: no idle stream between them
+                    self.engine.graph_begin()
+                    for _ in range(GRAPH_TICKS):
+                        self._tick_body()
+                    self.engine.graph_end_many(GRAPH_TICKS)
             self.native_graph = True
             return
         with torch.cuda.stream(self.stream):
