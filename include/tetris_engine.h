@@ -320,6 +320,16 @@ typedef struct trl_alphasame_heads {
     int32_t use_tanh;                     /* output activation of the value head: 0 sigmoid, 1 tanh     */
 } trl_alphasame_heads;
 int  trl_mcts_expand_alphasame(trl_engine *h, const float *dev_z, const float *dev_vec, const trl_alphasame_heads *w);
+/* the same followed by trl_mcts_select_need of the next simulation, in one launch: a slot goes on to its next selection
+ * without waiting for the slowest expand of the batch.  dev_vec is read (the evaluated leaf's features), then overwritten
+ * with the next leaf's; dev_grids / dev_need as in trl_mcts_select_need.  A tick is then {tower, this call}, after one
+ * trl_mcts_select_need for the very first simulation.                                                               */
+int  trl_mcts_expand_alphasame_select(trl_engine *h, const float *dev_z, float *dev_vec, const trl_alphasame_heads *w,
+                                      float *dev_grids, uint8_t *dev_need);
+/* every slot starts a new search at its next selection (the state after trl_mcts_create).  A caller that replaces the
+ * game states (trl_env_set_state / trl_env_reset / trl_env_step) while a selection made by the call above is pending
+ * discards it with this call and selects again (trl_mcts_select_need).                                              */
+int  trl_mcts_restart(trl_engine *h);
 /* the same for the slots with dev_slot_mask[slot] == want only (uint8 per slot): matches between two networks run one
  * launch per network (battle_networks, ai.py:1975-2052: a player's searches use that player's network); `last` = 1
  * on the launch that completes the tick. */

@@ -110,6 +110,34 @@ def test_graph_and_eager_ticks_agree():
     assert np.array_equal(out[0]["chosen"], out[1]["chosen"]) and np.array_equal(out[0]["visits"], out[1]["visits"])
 
 
+def test_fused_expand_select_tick_is_bit_identical(monkeypatch):
+    """the production tick issues the expand of one simulation and the selection of the next as ONE launch
+    (trl_mcts_expand_alphasame_select) inside graphs of eight ticks; the same games come out as with the three-kernel tick,
+    one graph launch per tick, and as with eager launches -- also when the states are written under a pending selection"""
+    from tetris_rl_amd import selfplay
+    torch.manual_seed(0)
+    net = trl.AlphaSame(trl.AlphaSameConfig(blocks=2, filters=16)).cuda().prepare()
+    cfg = trl.Config(visual=False, model="pytorch", model_config=trl.AlphaSameConfig(blocks=2, filters=16), MAX_ITER=16, training=True)
+    out = []
+    for fuse, ticks_per_graph, use_graph in ((True, 8, True), (False, 1, True), (False, 1, False)):
+        monkeypatch.setattr(selfplay, "FUSE_SELECT", fuse)
+        monkeypatch.setattr(selfplay, "GRAPH_TICKS", ticks_per_graph)
+        sp = trl.SelfPlay(cfg, net, 48, seed=11, use_graph=use_graph, auto_reset=True)
+        assert sp.fused_select == fuse and sp.heads is not None
+        sp.engine.set_state(sp.engine.get_state())       # an outside write to the states: the pending selection is redone
+        sp.tick(37)                                      # 4 long graphs + 5 single ticks
+        sp.tick(300)
+        st = sp.stats()
+        r = sp.drain()
+        r = r[np.lexsort((r["ply"], r["episode"], r["slot"]))]
+        out.append((r, st["simulations"]))
+        del sp
+    for r, sims in out[1:]:
+        assert sims == out[0][1] and len(r) == len(out[0][0]) > 48
+        for f in ("slot", "episode", "ply", "kind", "winner", "chosen", "saved", "n_children", "moves", "visits", "state"):
+            assert np.array_equal(r[f], out[0][0][f]), f
+
+
 def test_self_play_loop_generates_trains_and_gates(tmp_path, monkeypatch):
     """the whole outer loop of the reference (ai.py:2117-2198) on the device: data set -> learner -> gating
     match -> promotion, twice, with tiny settings"""

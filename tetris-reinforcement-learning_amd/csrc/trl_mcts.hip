@@ -139,9 +139,8 @@ __device__ unsigned long long g_mprof[16];     // [0..4] k_select phases, [8..12
 // ---- tick part A --------------------------------------------------------------------------------------
 // do_legal = 0: the legal-move search of the leaf is left to k_leaf_legal, which runs beside the net's tower on a second
 // stream (the tower needs the leaf's boards only); leaf_nlegal is filled in there.
-__global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *real, float *grids, float *vec, uint8_t *need,
-                                                  int do_legal) {
-    __shared__ SelectShared sh;
+static __device__ __forceinline__ void select_body(SelectShared &sh, const DevMcts &M, trl_game_state *real, float *grids, float *vec,
+                                                   uint8_t *need, int do_legal) {
     const int tid = threadIdx.x, slot = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t nb = (size_t)slot * M.max_nodes;
     trl_game_state *pool = M.pool + (size_t)slot * M.cap_states;
@@ -327,9 +326,14 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
         }
         if (kind == 0 && do_legal && sh.b.overflow) { c.overflow = 1; atomicAdd(&M.counters[5], 1ull); }     // a legal-move cap was hit
         M.ctl[slot] = c;
-        atomicAdd(&M.counters[0], 1ull);
     }
     MPROF_T(ms5); MPROF_ADD(4, ms4, ms5);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *real, float *grids, float *vec, uint8_t *need,
+                                                  int do_legal) {
+    __shared__ SelectShared sh;
+    select_body(sh, M, real, grids, vec, need, do_legal);
 }
 
 // the legal-move search of every slot's current leaf (get_move_matrix + get_move_list, ai.py:414-417), split off k_select:
@@ -371,10 +375,10 @@ struct HeadsDev {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *real, const float *values, const float *policy,
-                                                  const float *head_w, const float *head_b, int feat_dim, HeadsDev H) {
+static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMcts &M, trl_game_state *real, const float *values,
+                                                   const float *policy, const float *head_w, const float *head_b, int feat_dim,
+                                                   const HeadsDev &H) {
     constexpr bool HEAD = (MODE >= 1);
-    __shared__ ExpandShared sh;
     const int tid = threadIdx.x, slot = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t nb = (size_t)slot * M.max_nodes;
     trl_game_state *pool = M.pool + (size_t)slot * M.cap_states;
@@ -384,6 +388,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
     if (tid == 0) sh.ctl = M.ctl[slot];
     __syncthreads();
     if (sh.ctl.phase != 1) return;
+    if (tid == 0) atomicAdd(&M.counters[0], 1ull);         // simulations = selections whose result was backed up
     const int leaf = sh.ctl.leaf, kind = sh.ctl.leaf_kind;
     const double value_min = cfg.use_tanh ? -1.0 : 0.0;                     // Config.value_min; negate_value below (ai.py:198-216)
     const bool tanh_range = cfg.use_tanh != 0;
@@ -783,6 +788,27 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
     MPROF_T(me5); MPROF_ADD(12, me4, me5);
 }
 
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *real, const float *values, const float *policy,
+                                                  const float *head_w, const float *head_b, int feat_dim, HeadsDev H) {
+    __shared__ ExpandShared sh;
+    expand_body<MODE>(sh, M, real, values, policy, head_w, head_b, feat_dim, H);
+}
+
+// Tick part B of one simulation and part A of the next in one launch (the production tick with an AlphaSame net): a slot
+// that is done with its expand goes on to its next selection instead of waiting for the slowest expand of the launch, and
+// the launch ends with the slowest expand + select of one slot, not with the slowest expand plus the slowest select.
+// `vec` is read by the expand (the leaf's feature vector) before the same workgroup's select overwrites it; `grids` were
+// consumed by the tower that ran before this launch.
+__global__ __launch_bounds__(BLOCK) void k_expand_select(DevMcts M, trl_game_state *real, float *vec, const float *z,
+                                                         const float *head_w, const float *head_b, HeadsDev H, float *grids,
+                                                         uint8_t *need) {
+    __shared__ union U { ExpandShared e; SelectShared s; __device__ U() {} } sh;
+    expand_body<2>(sh.e, M, real, vec, z, head_w, head_b, 521, H);
+    __syncthreads();                               // the tree and the slot's control block are in memory; the LDS block changes hands
+    select_body(sh.s, M, real, grids, vec, need, 1);
+}
+
 // tower-output cache.  z: [2][n][400] as written by the tower for the boards flagged by k_select.  Afterwards
 // z[0] / z[1] hold the outputs for the side to move / the other player of every evaluated leaf, and the
 // leaf's cache entry holds both (indexed by absolute player).
@@ -950,6 +976,15 @@ int trl_mcts_create(trl_engine *h, const trl_mcts_config *cfg) {
     return TRL_OK;
 }
 
+// every slot starts a new search at its next selection (the state after trl_mcts_create): for callers that replace the
+// game states (trl_env_set_state / _reset / _step) while a selection made by trl_mcts_expand_alphasame_select is pending
+int trl_mcts_restart(trl_engine *h) {
+    if (!h || !h->mcts) return fail(TRL_E_INVALID, "trl_mcts_restart: %s", "no search attached");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    HIPCHK(hipMemsetAsync(h->mcts->d.ctl, 0, (size_t)h->cfg.n_games * sizeof(SlotCtl), h->stream));
+    return TRL_OK;
+}
+
 int trl_mcts_select(trl_engine *h, float *dev_grids, float *dev_vec) {
     return trl_mcts_select_need(h, dev_grids, dev_vec, nullptr);
 }
@@ -1061,6 +1096,22 @@ int trl_mcts_expand_alphasame_masked(trl_engine *h, const float *dev_z, const fl
 
 int trl_mcts_expand_alphasame(trl_engine *h, const float *dev_z, const float *dev_vec, const trl_alphasame_heads *w) {
     return trl_mcts_expand_alphasame_masked(h, dev_z, dev_vec, w, nullptr, 0, 1);
+}
+
+// trl_mcts_expand_alphasame followed by trl_mcts_select_need of the next simulation, as one launch (k_expand_select)
+int trl_mcts_expand_alphasame_select(trl_engine *h, const float *dev_z, float *dev_vec, const trl_alphasame_heads *w,
+                                     float *dev_grids, uint8_t *dev_need) {
+    if (!h || !h->mcts || !dev_z || !dev_vec || !w || !dev_grids)
+        return fail(TRL_E_INVALID, "trl_mcts_expand_alphasame_select: %s", "null argument / no search attached");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    if (h->mcts->d.zdim != 400) return fail(TRL_E_STATE, "%s", "trl_mcts_expand_alphasame_select needs the 400-float tower cache (trl_mcts_zcache_dim)");
+    if (h->mcts->fork_legal) return fail(TRL_E_STATE, "%s", "trl_mcts_expand_alphasame_select: not with trl_mcts_fork_legal");
+    HeadsDev H{w->oside_w, w->oside_b, w->value0_w, w->value0_b, w->value3_w, w->value3_b, w->use_tanh, nullptr, 0};
+    hipLaunchKernelGGL(k_expand_select, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_vec,
+                       dev_z, w->policy_w, w->policy_b, H, dev_grids, dev_need);
+    HIPCHK(hipGetLastError());
+    h->mcts->ticks++;
+    return TRL_OK;
 }
 
 int trl_mcts_drain_records(trl_engine *h, trl_record *host_out, int cap, int *n_out) {

@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "trl_env_rollout_random", "trl_last_kernel_ms",
     "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_expand_head", "trl_mcts_drain_records", "trl_mcts_drain_records_dev", "trl_mcts_get_stats",
     "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16", "trl_alphasame_trunk16_need", "trl_alphasame_trunk16_split", "trl_trunk_wide_split", "trl_alphasame_trunk", "trl_resnet_trunk", "trl_graph_begin", "trl_graph_end", "trl_graph_end_many", "trl_graph_launch",
-    "trl_mcts_select_need", "trl_mcts_fork_legal", "trl_mcts_expand_alphasame_masked", "trl_mcts_zcache", "trl_mcts_zcache_dim", "trl_mcts_expand_alphasame",
+    "trl_mcts_select_need", "trl_mcts_fork_legal", "trl_mcts_expand_alphasame_masked", "trl_mcts_zcache", "trl_mcts_zcache_dim", "trl_mcts_expand_alphasame", "trl_mcts_expand_alphasame_select", "trl_mcts_restart",
 ]
 
 GRID_FLOATS = 400
@@ -140,6 +140,8 @@ def load_library(path=None):
     L.trl_graph_end_many.argtypes = [C.c_void_p, C.c_int]
     L.trl_graph_launch.argtypes = [C.c_void_p, C.c_int]
     L.trl_mcts_expand_alphasame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(TrlAlphaSameHeads)]
+    L.trl_mcts_restart.argtypes = [C.c_void_p]
+    L.trl_mcts_expand_alphasame_select.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(TrlAlphaSameHeads), C.c_void_p, C.c_void_p]
     L.trl_mcts_expand_alphasame_masked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(TrlAlphaSameHeads),
                                                    C.c_void_p, C.c_int, C.c_int]
     L.trl_alphasame_trunk16_need.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -175,6 +177,7 @@ class Engine:
         self.seed = int(seed)
         cfg = TrlConfig(self.n_games, RULESETS[ruleset], device, 0, self.seed, stream)
         self._h = C.c_void_p()
+        self.state_epoch = 0            # counts the calls that replace or advance the game states from outside the search
         _check(self._L, self._L.trl_engine_create(C.byref(cfg), C.byref(self._h)), "trl_engine_create")
 
     def close(self):
@@ -203,6 +206,7 @@ class Engine:
                 raise ValueError("streams must have shape (n_games,)")
             sp = streams.ctypes.data
         _check(self._L, self._L.trl_env_reset(self._h, sp), "trl_env_reset")
+        self.state_epoch += 1
 
     def get_state(self):
         out = np.empty((self.n_games, STATE_BYTES), dtype=np.uint8)
@@ -214,6 +218,7 @@ class Engine:
         if states.shape != (self.n_games, STATE_BYTES):
             raise ValueError("states must have shape (n_games, %d)" % STATE_BYTES)
         _check(self._L, self._L.trl_env_set_state(self._h, states.ctypes.data), "trl_env_set_state")
+        self.state_epoch += 1
 
     def legal_moves(self, algo="convolutional"):
         """algo: 'convolutional' (Config.move_algorithm's default, what the search uses) or 'brute-force'
@@ -232,11 +237,13 @@ class Engine:
             raise ValueError("moves must have shape (n_games,)")
         _check(self._L, self._L.trl_env_step(self._h, moves.ctypes.data, int(bool(add_bag)), int(bool(check_legal))),
                "trl_env_step")
+        self.state_epoch += 1
 
     def rollout_random(self, n_plies, max_plies=2000, sync=True):
         steps = C.c_uint64(0)
         _check(self._L, self._L.trl_env_rollout_random(self._h, int(n_plies), int(max_plies),
                                                         C.byref(steps) if sync else None), "trl_env_rollout_random")
+        self.state_epoch += 1
         return steps.value if sync else None
 
     def last_kernel_ms(self):
@@ -291,6 +298,13 @@ class Engine:
 
     def mcts_expand_alphasame(self, z_ptr, vec_ptr, heads):
         _check(self._L, self._L.trl_mcts_expand_alphasame(self._h, z_ptr, vec_ptr, C.byref(heads)), "trl_mcts_expand_alphasame")
+
+    def mcts_restart(self):
+        _check(self._L, self._L.trl_mcts_restart(self._h), "trl_mcts_restart")
+
+    def mcts_expand_alphasame_select(self, z_ptr, vec_ptr, heads, grids_ptr, need_ptr):
+        _check(self._L, self._L.trl_mcts_expand_alphasame_select(self._h, z_ptr, vec_ptr, C.byref(heads), grids_ptr, need_ptr),
+               "trl_mcts_expand_alphasame_select")
 
     def mcts_expand_alphasame_masked(self, z_ptr, vec_ptr, heads, mask_ptr, want, last):
         _check(self._L, self._L.trl_mcts_expand_alphasame_masked(self._h, z_ptr, vec_ptr, C.byref(heads), mask_ptr, int(want), int(last)),

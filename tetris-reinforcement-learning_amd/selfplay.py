@@ -119,6 +119,7 @@ def derive_seed(base, *parts):
 
 
 # ---- the tick loop ----------------------------------------------------------------------------------------
+FUSE_SELECT = os.environ.get("TRL_FUSE_SELECT", "1") != "0"   # native tick: expand + next select as one launch
 GRAPH_TICKS = int(os.environ.get("TRL_GRAPH_TICKS", "8"))      # ticks per launch of the long tick graph (1: single-tick graph only)
 
 
@@ -171,6 +172,7 @@ class SelfPlay:
         self.stream.synchronize()
         self.graph = None
         self.native_graph = False
+        self.fused_select = False
         self.ticks = 0
         if use_graph:
             self._capture()
@@ -178,6 +180,11 @@ class SelfPlay:
     def _tick_body(self):
         e = self.engine
         # v / p / x / z live in the stream-ordered allocator (a fixed address inside a captured graph)
+        if self.fused_select:
+            # the selection of this simulation was made by the previous tick's launch (or by _capture for the first one)
+            self.net.tower_need(self.grids, self.need, out=self.z)
+            e.mcts_expand_alphasame_select(self.z.data_ptr(), self.vec.data_ptr(), self.heads, self.grids.data_ptr(), self.need.data_ptr())
+            return
         if self.tower_cache:
             e.mcts_select_need(self.grids.data_ptr(), self.vec.data_ptr(), self.need.data_ptr())
             if self.heads is not None:
@@ -207,6 +214,11 @@ class SelfPlay:
             # the tick is library kernels only: capture it with the library's own HIP graph (trl_graph_*); a
             # torch.cuda.CUDAGraph replay adds half a dozen small generator-state kernels of its own per replay
             with torch.cuda.stream(self.stream):
+                if FUSE_SELECT and not self.fork_legal:
+                    # expand of one simulation and select of the next in one launch (trl_mcts_expand_alphasame_select):
+                    # the first selection is made here, every tick after it is {tower, expand + select}
+                    self.engine.mcts_select_need(self.grids.data_ptr(), self.vec.data_ptr(), self.need.data_ptr())
+                    self.fused_select, self._select_epoch = True, self.engine.state_epoch
                 self.engine.graph_begin()
                 self._tick_body()
                 self.engine.graph_end()
@@ -228,6 +240,13 @@ class SelfPlay:
 
     def tick(self, n=1):
         torch = self.torch
+        if self.fused_select and self._select_epoch != self.engine.state_epoch:
+            # the game states were replaced from outside (set_state / reset / step) after the pending selection was made:
+            # drop it, start every slot's search over from the new states and select again
+            with torch.cuda.stream(self.stream):
+                self.engine.mcts_restart()
+                self.engine.mcts_select_need(self.grids.data_ptr(), self.vec.data_ptr(), self.need.data_ptr())
+            self._select_epoch = self.engine.state_epoch
         if self.native_graph:
             self.engine.graph_launch(n)
             self.ticks += n
