@@ -95,8 +95,10 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
     net = trl.AlphaSame(trl.AlphaSameConfig(blocks=10, filters=16))
     cfg = trl.Config(visual=False, model="pytorch", model_config=trl.AlphaSameConfig(blocks=10, filters=16),
                      MAX_ITER=160, training=True)
-    sp = trl.SelfPlay(cfg, net, n, seed=SEED, device=local_rank, streams=parallel.game_streams(rank, n),
-                      auto_reset=True, use_graph=True, record_capacity=1 << 17)
+    # the slots tick in two groups on two streams (selfplay.SelfPlayGroups): the search kernels of one beside the tower of the other
+    sp = trl.make_self_play(cfg, net, n, seed=SEED, device=local_rank, streams=parallel.game_streams(rank, n),
+                            auto_reset=True, use_graph=True, record_capacity=1 << 17)
+    groups = len(getattr(sp, "parts", [sp]))
     sp.tick(args.mcts_warmup)
     sp.drain()
     st0 = sp.stats()
@@ -131,7 +133,8 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
     moves = st1["moves"] - st0["moves"]
     sims = st1["simulations"] - st0["simulations"]
     # live timing of the dominant kernel (fused tower) with events on the stream it runs on
-    boards = sp.grids.reshape(2 * n, 1, 40, 10)
+    boards = sp.grids.reshape(-1, 1, 40, 10)               # one tower launch of the tick: both boards of a group's slots
+    nb = boards.shape[0]
     with torch.cuda.stream(sp.stream):
         sp.net.trunk(boards)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -145,11 +148,11 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
     elapsed, moves_total = parallel.reduce_job(elapsed, moves, dist, dev)
     _, sims_total = parallel.reduce_job(elapsed, sims, dist, dev)
     split = getattr(sp.net, "tower_mode", "fp32") == "split"
-    algo_tflops = TRUNK_FLOP_PER_BOARD * 2 * n / (trunk_ms * 1e-3) / 1e12
+    algo_tflops = TRUNK_FLOP_PER_BOARD * nb / (trunk_ms * 1e-3) / 1e12
     if split:
         # the tower runs on the f16 matrix instruction with every fp32 operand split in two halves (fp32 accuracy):
         # achieved = f16 matrix FLOPs executed, against the dense f16 peak; the algorithmic (fp32-equivalent) rate beside it
-        tflops, peak, kname = SPLIT_FLOP_PER_BOARD * 2 * n / (trunk_ms * 1e-3) / 1e12, MFMA_F16_PEAK_TFLOPS, "k_trunk16s"
+        tflops, peak, kname = SPLIT_FLOP_PER_BOARD * nb / (trunk_ms * 1e-3) / 1e12, MFMA_F16_PEAK_TFLOPS, "k_trunk16s"
     else:
         tflops, peak, kname = algo_tflops, MFMA_F32_PEAK_TFLOPS, "k_trunk16"
     return {
@@ -160,13 +163,13 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
         "config": {"workload": "C3: %d concurrent self-play games per GPU, MAX_ITER=160, training=True "
                                "(playout cap 400/80, root noise, temperature), AlphaSame blocks=10 filters=16 random init"
                                % n, "games_per_gpu": n, "ticks_timed": args.mcts_ticks, "moves_timed": moves_total,
-                   "simulations_timed": sims_total,
+                   "simulations_timed": sims_total, "slot_groups": groups,
                    "records_to_rank0_mb": round(gathered / 1e6, 1),
                    "parallelism": "games sharded by rank; move records gathered to rank 0 (dist.gather, GPU to GPU) in the timed region"},
         "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(tflops / peak, 4), "traffic": None, "kernel": kname,
                      "kernel_ms": round(trunk_ms, 4), "flop_per_board": SPLIT_FLOP_PER_BOARD if split else TRUNK_FLOP_PER_BOARD,
-                     "boards_per_launch": 2 * n, "algorithmic_tflops": round(algo_tflops, 2),
+                     "boards_per_launch": nb, "algorithmic_tflops": round(algo_tflops, 2),
                      "algorithmic_flop_per_board": TRUNK_FLOP_PER_BOARD,
                      "note": ("f16 matrix instructions on split fp32 operands (a = hi + lo / 2^11; 3 products per multiply, K 144 -> 160): "
                               "the algorithmic rate is %.2f x the fp32 matrix peak of %.1f TFLOP/s that bounded round 1's tower"

@@ -134,8 +134,43 @@ def test_fused_expand_select_tick_is_bit_identical(monkeypatch):
         del sp
     for r, sims in out[1:]:
         assert sims == out[0][1] and len(r) == len(out[0][0]) > 48
-        for f in ("slot", "episode", "ply", "kind", "winner", "chosen", "saved", "n_children", "moves", "visits", "state"):
+        for f in ("slot", "episode", "ply", "kind", "winner", "chosen", "saved", "n_children", "state"):
             assert np.array_equal(r[f], out[0][0][f]), f
+        valid = np.arange(512)[None, :] < r["n_children"][:, None]
+        assert np.array_equal(r["moves"][valid], out[0][0]["moves"][valid]) and np.array_equal(r["visits"][valid], out[0][0]["visits"][valid])
+
+
+def test_slot_groups_play_the_same_games():
+    """SelfPlayGroups: the slots of a job as two independently ticking groups (own engine, stream and graphs each) -- the same
+    games, records and counters as one SelfPlay over all slots, through the host drain and through the device drain"""
+    from tetris_rl_amd import selfplay, engine
+    torch.manual_seed(0)
+    net = trl.AlphaSame(trl.AlphaSameConfig(blocks=2, filters=16)).cuda().prepare()
+    cfg = trl.Config(visual=False, model="pytorch", model_config=trl.AlphaSameConfig(blocks=2, filters=16), MAX_ITER=16, training=True)
+    streams = np.arange(100, 164, dtype=np.uint32)
+    kw = dict(seed=21, streams=streams, auto_reset=True, episodes=(1, 40))       # slots 0..39 play two games, the rest one
+    one = trl.SelfPlay(cfg, net, 64, **kw)
+    two = trl.SelfPlayGroups(cfg, net, 64, 2, **kw)
+    assert [p.n for p in two.parts] == [32, 32] and selfplay.slot_groups(cfg, net, 1024) == 2 and selfplay.slot_groups(cfg, net, 64) == 1
+    got = []
+    for sp in (one, two):
+        recs = []
+        for i in range(6):
+            sp.tick(200)
+            if i % 2:
+                recs.append(sp.drain())
+            else:
+                t = sp.drain_dev().cpu().numpy()
+                recs.append(t.view(engine.RECORD_DTYPE))
+        r = np.concatenate(recs)
+        got.append((r[np.lexsort((r["kind"], r["ply"], r["episode"], r["slot"]))], sp.stats()))
+    (a, sa), (b, sb) = got
+    assert len(a) == len(b) > 64 and sa["games"] == sb["games"] > 64 and sa["moves"] == sb["moves"] and sa["simulations"] == sb["simulations"]
+    assert (a["episode"] == 1).any() and a["slot"].max() == 63              # second games ran; both groups' slots are there
+    for f in ("slot", "episode", "ply", "kind", "winner", "chosen", "saved", "n_children", "state"):
+        assert np.array_equal(a[f], b[f]), f
+    valid = np.arange(512)[None, :] < a["n_children"][:, None]               # the rest of a row is whatever the buffer held
+    assert np.array_equal(a["moves"][valid], b["moves"][valid]) and np.array_equal(a["visits"][valid], b["visits"][valid])
 
 
 def test_self_play_loop_generates_trains_and_gates(tmp_path, monkeypatch):

@@ -10,7 +10,7 @@ from . import build as _build_mod
 
 def build(force=False, verbose=False):
     return _build_mod.build(force=force, verbose=verbose)
-from .selfplay import (Config, SelfPlay, GameCollector, play_game, make_training_set, self_play_loop,  # noqa: F401,E402
+from .selfplay import (Config, SelfPlay, SelfPlayGroups, make_self_play, GameCollector, play_game, make_training_set, self_play_loop,  # noqa: F401,E402
                        instantiate_network, load_best_model, highest_model_number, highest_data_number, search_options,
                        games_from_records)
 from .nets import (AlphaSame, AlphaSameConfig, BaseResNet, BaseResNetConfig, AuxBaseResNet,  # noqa: F401,E402

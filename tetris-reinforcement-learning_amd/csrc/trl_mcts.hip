@@ -69,7 +69,7 @@ __device__ __forceinline__ double rng_unif(uint64_t seed, uint32_t stream, uint3
     uint64_t u = mix64(k ^ ((uint64_t)purpose << 56) ^ ctr);
     return ((double)(u >> 11) + 0.5) * (1.0 / 9007199254740992.0);
 }
-__device__ double gamma_draw(uint64_t seed, uint32_t stream, uint64_t base_ctr, double a) {
+__device__ __forceinline__ double gamma_draw(uint64_t seed, uint32_t stream, uint64_t base_ctr, double a) {
     double d = (a + 1.0) - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
     for (int attempt = 0; attempt < 64; attempt++) {
         uint64_t cc = (base_ctr * 64 + (uint64_t)attempt) * 4;
@@ -86,19 +86,29 @@ __device__ double gamma_draw(uint64_t seed, uint32_t stream, uint64_t base_ctr, 
     }
     return 0.0;
 }
-// numpy's pairwise float64 sum (np.sum of a contiguous 1-D array, ai.py:600)
-__device__ double np_sum(const double *a, int n) {
+// numpy's pairwise float64 sum (np.sum of a contiguous 1-D array, ai.py:600): blocks of at most 128 elements are summed
+// with eight running sums, longer arrays are halved (at a multiple of 8) -- two levels of halving cover n <= 512 =
+// TRL_MAX_LEGAL, written out so that nothing is called and no array is indexed at run time
+__device__ __forceinline__ double np_sum_block(const double *a, int n) {           // n <= 128
     if (n < 8) { double r = 0.0; for (int i = 0; i < n; i++) r += a[i]; return r; }
-    if (n <= 128) {
-        double r[8]; int i;
-        for (i = 0; i < 8; i++) r[i] = a[i];
-        for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; j++) r[j] += a[i + j];
-        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; i++) res += a[i];
-        return res;
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3]; r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
     }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+__device__ __forceinline__ double np_sum_256(const double *a, int n) {             // n <= 256
+    if (n <= 128) return np_sum_block(a, n);
     int n2 = n / 2; n2 -= n2 % 8;
-    return np_sum(a, n2) + np_sum(a + n2, n - n2);       // depth <= 2 for n <= 512
+    return np_sum_block(a, n2) + np_sum_block(a + n2, n - n2);
+}
+__device__ __forceinline__ double np_sum(const double *a, int n) {                 // n <= 512
+    if (n <= 128) return np_sum_block(a, n);
+    int n2 = n / 2; n2 -= n2 % 8;
+    return np_sum_256(a, n2) + np_sum_256(a + n2, n - n2);
 }
 
 // ---- shared memory of the two kernels ---------------------------------------------------------------
@@ -800,7 +810,7 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
 // the launch ends with the slowest expand + select of one slot, not with the slowest expand plus the slowest select.
 // `vec` is read by the expand (the leaf's feature vector) before the same workgroup's select overwrites it; `grids` were
 // consumed by the tower that ran before this launch.
-__global__ __launch_bounds__(BLOCK) void k_expand_select(DevMcts M, trl_game_state *real, float *vec, const float *z,
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_expand_select(DevMcts M, trl_game_state *real, float *vec, const float *z,
                                                          const float *head_w, const float *head_b, HeadsDev H, float *grids,
                                                          uint8_t *need) {
     __shared__ union U { ExpandShared e; SelectShared s; __device__ U() {} } sh;

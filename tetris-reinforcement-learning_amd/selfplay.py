@@ -281,6 +281,91 @@ class SelfPlay:
         return self.engine.mcts_stats()
 
 
+class SelfPlayGroups:
+    """The slots of a job as G independently ticking SelfPlay groups, each with its own engine, stream and tick graphs:
+    the latency-bound search kernels of one group run beside the throughput-bound tower of another (C3, 1024 slots:
+    0.201 -> 0.178 ms per round of ticks with two groups, scripts/mcts_groups_probe.py).  That needs the search kernel to
+    fit the registers the tower's two workgroups per CU leave free (112 VGPRs: k_expand_select).  Same interface as
+    SelfPlay for the callers that run whole jobs (tick / drain / drain_dev / stats / synchronize); group g owns the global
+    slots [g * m, (g + 1) * m) with their RNG streams, so the games -- and, after the slot numbers are shifted back, the
+    records -- are those of one SelfPlay over all slots."""
+
+    def __init__(self, config, network, n_slots, groups, streams=None, episodes=(0, 0), **kw):
+        if n_slots % groups:
+            raise ValueError("n_slots must be a multiple of the number of groups")
+        self.n, self.m = int(n_slots), int(n_slots) // groups
+        if streams is None:
+            streams = np.arange(self.n, dtype=np.uint32)
+        streams = np.ascontiguousarray(streams, dtype=np.uint32)
+        base, extra = int(episodes[0]), int(episodes[1])
+        self.parts = []
+        for g in range(groups):
+            lo = g * self.m
+            part_extra = min(max(extra - lo, 0), self.m)           # slot s plays base + (s < extra) games, s global
+            self.parts.append(SelfPlay(config, network, self.m, streams=streams[lo:lo + self.m], episodes=(base, part_extra), **kw))
+        p0 = self.parts[0]
+        self.torch, self.device, self.net, self.config = p0.torch, p0.device, p0.net, config
+        self.stream, self.grids, self.heads = p0.stream, p0.grids, p0.heads        # group 0's: what a probe of the tower looks at
+        self.ticks = 0
+
+    def tick(self, n=1):
+        for p in self.parts:
+            p.tick(n)
+        self.ticks += n
+
+    def synchronize(self):
+        for p in self.parts:
+            p.synchronize()
+
+    def drain(self):
+        out = []
+        for g, p in enumerate(self.parts):
+            r = p.drain()
+            if len(r):
+                r = r.copy()
+                r["slot"] += g * self.m
+                out.append(r)
+        return np.concatenate(out) if out else np.zeros(0, dtype=_eng.RECORD_DTYPE)
+
+    def drain_dev(self):
+        torch, size = self.torch, _eng.RECORD_DTYPE.itemsize
+        out = []
+        for g, p in enumerate(self.parts):
+            t = p.drain_dev()
+            if t.numel() and g:
+                with torch.cuda.stream(p.stream):
+                    t.view(-1, size)[:, :4].view(torch.int32).add_(g * self.m)        # the record's slot field (first word)
+            p.stream.synchronize()
+            out.append(t)
+        with torch.cuda.stream(self.stream):
+            return torch.cat(out) if len(out) > 1 else out[0]
+
+    def stats(self):
+        sts = [p.stats() for p in self.parts]
+        out = {k: sum(st[k] for st in sts) for k in sts[0]}
+        out["ticks"] = sts[0]["ticks"]                                   # rounds of ticks, not their sum over the groups
+        out["max_nodes_used"] = max(st["max_nodes_used"] for st in sts)
+        return out
+
+
+def slot_groups(config, network, n_slots):
+    """how many groups a job's slots are ticked in: TRL_SLOT_GROUPS, or 2 where it pays -- the all-native tick of a
+    16-filter AlphaSame (two tower workgroups per CU leave registers for the search kernel) with at least 512 slots;
+    the 64-filter tower owns its CU (138 KB of LDS, 500 registers per SIMD) and gains nothing"""
+    env = os.environ.get("TRL_SLOT_GROUPS", "auto")
+    if env != "auto":
+        return max(1, int(env))
+    mc = getattr(network, "model_config", None)
+    native16 = type(network).__name__ == "AlphaSame" and getattr(mc, "filters", 0) == 16 and getattr(mc, "kernels", 1) == 1
+    return 2 if (native16 and n_slots >= 512 and n_slots % 2 == 0) else 1
+
+
+def make_self_play(config, network, n_slots, **kw):
+    """SelfPlay, or SelfPlayGroups over the same slots when slot_groups() says so"""
+    g = slot_groups(config, network, n_slots)
+    return SelfPlayGroups(config, network, n_slots, g, **kw) if g > 1 else SelfPlay(config, network, n_slots, **kw)
+
+
 class GameCollector:
     """Groups the device's record stream into finished games and builds the reference's per-game
     `data` lists (ai.py:1613-1695)."""
@@ -389,8 +474,8 @@ def _play_collect(config, network, num_games, seed, device=0, max_slots=1024, st
     base, extra = divmod(int(num_games), slots)
     if base + (1 if extra else 0) > 256:
         raise ValueError("more than 256 games per slot: raise max_slots (episode e of a slot runs on RNG stream + e * 2^24)")
-    sp = SelfPlay(config, network, slots, seed=seed, device=device, streams=streams, auto_reset=num_games > slots,
-                  episodes=(base, extra) if num_games > slots else (0, 0))
+    sp = make_self_play(config, network, slots, seed=seed, device=device, streams=streams, auto_reset=num_games > slots,
+                        episodes=(base, extra) if num_games > slots else (0, 0))
     col = GameCollector(config, as_text=as_text, packed_only=packed_only) if rank == 0 else None
     nccl = multi and dist.get_backend() == "nccl"
     cdev = sp.device if nccl else None
