@@ -261,15 +261,17 @@ __global__ __launch_bounds__(TRUNK_THREADS, 3) void k_trunk16(const float *__res
 // 2^-11 |a|, rounded again to 11 bits; the scale keeps lo a normal number, so nothing depends on f16 denormals).  With
 // activations and weights both split,
 //     a * w = hi_a hi_w + (lo_a hi_w + hi_a lo_w) / 2^11 + O(2^-22),
-// three v_mfma_f32_16x16x32_f16 (products of halves are exact in fp32, accumulation is fp32) into two accumulators:
-// main (+= hi hi) and corr (+= lo hi + hi lo), result = main + corr / 2^11.  Measured against the reference's logits
-// (tests/golden/net.npz, net_deep.npz): 2.2e-7 max error, the fp32 MFMA tower has 2.4e-7 (a 3-product bf16 split: 3e-6
+// three v_mfma_f32_16x16x32_f16 (products of halves are exact in fp32, accumulation is fp32) into ONE accumulator: the
+// weights' hi half is scaled by 2^11 in registers, so hi_a (2^11 hi_w), lo_a hi_w and hi_a lo_w all carry the factor 2^11
+// (lo = 2^11 (x - hi) on both sides) and the sum is scaled back once per conv.  Measured against the reference's logits
+// (tests/golden/net.npz, net_deep.npz): 1.8e-7 max error, the fp32 MFMA tower has 2.1e-7 (a 3-product bf16 split: 3e-6
 // to 1.6e-5, rejected; 6 bf16 products match fp32 but cost twice the MFMAs of this scheme).
 //   * K = 144 = 9 taps x 16 channels in 5 K-steps of 32 (two taps each, the tenth half-step has zero weights): a
-//     lane's A fragment is 8 consecutive channels of one tap = ONE ds_read_b128 from the hi plane and one from the lo
-//     plane (rows of [12 hi positions | 12 lo positions][16 channels] halves at a pitch of 26 positions, 34 KB);
+//     lane's activation fragment is 8 consecutive channels of one tap = ONE ds_read_b128 for the hi half and one for the
+//     lo half (rows of [12 hi positions | 12 lo positions][16 channels] halves at a pitch of 26 positions, 34 KB);
 //   * 15 MFMAs of 16 cycles per (tile, conv) instead of 36 of 32 cycles: 4.8x fewer matrix-pipe cycles;
-//   * B operand: 5 K-steps x {hi, lo} x 4 VGPRs per lane, packed on the host (nets.AlphaSame._pack_tower_split).
+//   * weights: 5 K-steps x {hi, lo} x 4 VGPRs per lane, packed on the host (nets.AlphaSame._pack_tower_split), streamed
+//     from L2 one K-step ahead (conv_step).
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr int HST = 16;                          // halves per position
 // Row pitch of the split planes, in positions: a row holds its 12 hi positions (10 + the zero border) at 0..11 and its 12
