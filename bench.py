@@ -172,7 +172,9 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
                      "boards_per_launch": nb, "algorithmic_tflops": round(algo_tflops, 2),
                      "algorithmic_flop_per_board": TRUNK_FLOP_PER_BOARD,
                      "note": ("f16 matrix instructions on split fp32 operands (a = hi + lo / 2^11; 3 products per multiply, K 144 -> 160): "
-                              "the algorithmic rate is %.2f x the fp32 matrix peak of %.1f TFLOP/s that bounded round 1's tower"
+                              "the algorithmic rate is %.2f x the fp32 matrix peak of %.1f TFLOP/s that bounded round 1's tower; "
+                              "kernel_ms = one launch over ALL boards of a slot group, timed alone after the run -- inside a tick the "
+                              "tower skips the boards whose output is cached (about half: the kernel-trace average is about half of this)"
                               % (algo_tflops / MFMA_F32_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS)) if split else "fp32 matrix instructions"},
     }
 
