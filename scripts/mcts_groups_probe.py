@@ -4,11 +4,13 @@ import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import tetris_rl_amd as trl
-from tetris_rl_amd import parallel
+from tetris_rl_amd import parallel, engine
+if len(sys.argv) > 1:                                   # another build of the library (A/B in one box)
+    engine._lib = engine.load_library(sys.argv[1])
 torch.manual_seed(0)
 net = trl.AlphaSame(trl.AlphaSameConfig(blocks=10, filters=16))
 cfg = trl.Config(visual=False, model='pytorch', model_config=trl.AlphaSameConfig(blocks=10, filters=16), MAX_ITER=160, training=True)
-for total, groups in ((1024, 1), (1024, 2), (2048, 1), (2048, 2), (3072, 3), (4096, 4)):
+for total, groups in ((1024, 1), (1024, 2), (2048, 1), (2048, 2), (3072, 3), (4096, 4))[:2 if len(sys.argv) > 1 else 6]:
     n = total // groups
     sps = [trl.SelfPlay(cfg, net, n, seed=20260630, streams=parallel.game_streams(g, n), use_graph=True, record_capacity=65536) for g in range(groups)]
     for sp in sps: sp.tick(20)

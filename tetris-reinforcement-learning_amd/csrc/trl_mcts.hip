@@ -805,6 +805,11 @@ __global__ __launch_bounds__(BLOCK) void k_expand(DevMcts M, trl_game_state *rea
     expand_body<MODE>(sh, M, real, values, policy, head_w, head_b, feat_dim, H);
 }
 
+#ifndef TRL_SEARCH_PRIO
+#define TRL_SEARCH_PRIO 3
+#endif
+constexpr int SEARCH_PRIO = TRL_SEARCH_PRIO;
+
 // Tick part B of one simulation and part A of the next in one launch (the production tick with an AlphaSame net): a slot
 // that is done with its expand goes on to its next selection instead of waiting for the slowest expand of the launch, and
 // the launch ends with the slowest expand + select of one slot, not with the slowest expand plus the slowest select.
@@ -814,6 +819,9 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) v
                                                          const float *head_w, const float *head_b, HeadsDev H, float *grids,
                                                          uint8_t *need) {
     __shared__ union U { ExpandShared e; SelectShared s; __device__ U() {} } sh;
+    // latency-bound (two waves per slot, long dependent chains): when the other slot group's tower shares the SIMD, these
+    // waves go first -- they issue rarely, so the tower loses little and the search chain of the tick gets shorter
+    __builtin_amdgcn_s_setprio(SEARCH_PRIO);
     expand_body<2>(sh.e, M, real, vec, z, head_w, head_b, 521, H);
     __syncthreads();                               // the tree and the slot's control block are in memory; the LDS block changes hands
     select_body(sh.s, M, real, grids, vec, need, 1);
