@@ -6,7 +6,7 @@ import tetris_rl_amd as trl
 from tetris_rl_amd import engine
 L = engine.load_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_prof", "libtrl_prof.so"))
 engine._lib = L
-n = 1024
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024         # 256: one workgroup per CU, a search alone on its SIMD (latency)
 e = trl.Engine(n, seed=20260630); e.reset(); e.rollout_random(30)
 buf = (C.c_ulonglong * 16)()
 L.trl_debug_prof(buf, 1)
