@@ -116,8 +116,15 @@ def test_fused_expand_select_tick_is_bit_identical(monkeypatch):
     one graph launch per tick, and as with eager launches -- also when the states are written under a pending selection"""
     from tetris_rl_amd import selfplay
     torch.manual_seed(0)
-    net = trl.AlphaSame(trl.AlphaSameConfig(blocks=2, filters=16)).cuda().prepare()
-    cfg = trl.Config(visual=False, model="pytorch", model_config=trl.AlphaSameConfig(blocks=2, filters=16), MAX_ITER=16, training=True)
+    _fused_against_classic(monkeypatch, selfplay, trl.AlphaSame(trl.AlphaSameConfig(blocks=2, filters=16)).cuda().prepare(),
+                           dict(training=True))
+    # the value range -1..1 and the random starting moves go through the same launch
+    _fused_against_classic(monkeypatch, selfplay, trl.AlphaSame(trl.AlphaSameConfig(blocks=2, filters=16), use_tanh=True).cuda().prepare(),
+                           dict(training=False, use_tanh=True, use_random_starting_moves=True))
+
+
+def _fused_against_classic(monkeypatch, selfplay, net, options):
+    cfg = trl.Config(visual=False, model="pytorch", model_config=trl.AlphaSameConfig(blocks=2, filters=16), MAX_ITER=16, **options)
     out = []
     for fuse, ticks_per_graph, use_graph in ((True, 8, True), (False, 1, True), (False, 1, False)):
         monkeypatch.setattr(selfplay, "FUSE_SELECT", fuse)
