@@ -171,6 +171,7 @@ class SelfPlay:
             self.engine.mcts_fork_legal(True)
         self.stream.synchronize()
         self.graph = None
+        self.graph_many = None
         self.native_graph = False
         self.fused_select = False
         self.ticks = 0
@@ -237,6 +238,12 @@ class SelfPlay:
         with torch.cuda.graph(g, stream=self.stream):
             self._tick_body()
         self.graph = g
+        if GRAPH_TICKS > 1:                           # and GRAPH_TICKS ticks in one graph: no idle stream between them
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.stream):
+                for _ in range(GRAPH_TICKS):
+                    self._tick_body()
+            self.graph_many = g
 
     def tick(self, n=1):
         torch = self.torch
@@ -252,7 +259,12 @@ class SelfPlay:
             self.ticks += n
             return
         with torch.cuda.stream(self.stream):           # graph replays launch on the current stream
-            for _ in range(n):
+            left = n
+            if self.graph_many is not None:
+                for _ in range(left // GRAPH_TICKS):
+                    self.graph_many.replay()
+                left %= GRAPH_TICKS
+            for _ in range(left):
                 if self.graph is not None:
                     self.graph.replay()
                 else:
