@@ -82,6 +82,7 @@ MFMA_F16_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: dense BF16 / F16 matrix pe
 TRUNK_FLOP_PER_BOARD = 2 * 400 * (25 * 16 + 20 * 144 * 16 + 16)     # conv5x5 + 20 conv3x3 + conv1x1 = 37.2 MFLOP
 # k_trunk16s executes every 3x3-conv product as three f16 products (hi hi, lo hi, hi lo) over K padded from 144 to 160
 SPLIT_FLOP_PER_BOARD = 2 * 400 * (25 * 16 + 20 * 160 * 16 * 3 + 16)
+SPLIT_NOPAD_FLOP_PER_BOARD = 2 * 400 * (25 * 16 + 20 * 144 * 16 * 3 + 16)       # the three products, without the padding of K
 
 
 def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
@@ -128,25 +129,30 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
     barrier()
     elapsed = time.perf_counter() - t0
     st1 = sp.stats()
-    if st1["overflow"] or st1["records_dropped"]:
-        raise SystemExit("tree / record capacity overflowed during the MCTS benchmark: results invalid")
+    if st1["overflow"] or st1["records_dropped"] or st1.get("tower_overflow"):
+        raise SystemExit("tree / record capacity (or the split towers' activation range) overflowed during the MCTS benchmark: results invalid")
     moves = st1["moves"] - st0["moves"]
     sims = st1["simulations"] - st0["simulations"]
     # live timing of the dominant kernel (fused tower) with events on the stream it runs on
     boards = sp.grids.reshape(-1, 1, 40, 10)               # one tower launch of the tick: both boards of a group's slots
     nb = boards.shape[0]
     with torch.cuda.stream(sp.stream):
-        sp.net.trunk(boards)
+        sp.net._trunk_hip(boards, sp.net._folded["packed_tower"])       # the launch alone (trunk() also waits and reads the range guard)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 50
         e0.record(sp.stream)
         for _ in range(reps):
-            sp.net.trunk(boards)
+            sp.net._trunk_hip(boards, sp.net._folded["packed_tower"])       # the launch alone (trunk() also waits and reads the range guard)
         e1.record(sp.stream)
     e1.synchronize()
     trunk_ms = e0.elapsed_time(e1) / reps
+    tk = time_tick_kernels(sp)                              # (tower ms, search-kernel ms, slots) of one group's tick, live
+    my_rate = moves / elapsed
     elapsed, moves_total = parallel.reduce_job(elapsed, moves, dist, dev)
     _, sims_total = parallel.reduce_job(elapsed, sims, dist, dev)
+    per_rank = None
+    if parallel.active(dist):
+        per_rank = [round(v / 1e3, 1) for v in parallel.all_gather_ints([int(my_rate * 1e3)], dist, dev)[:, 0]]
     split = getattr(sp.net, "tower_mode", "fp32") == "split"
     algo_tflops = TRUNK_FLOP_PER_BOARD * nb / (trunk_ms * 1e-3) / 1e12
     if split:
@@ -155,7 +161,45 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
         tflops, peak, kname = SPLIT_FLOP_PER_BOARD * nb / (trunk_ms * 1e-3) / 1e12, MFMA_F16_PEAK_TFLOPS, "k_trunk16s"
     else:
         tflops, peak, kname = algo_tflops, MFMA_F32_PEAK_TFLOPS, "k_trunk16"
-    return {
+    tower_block = {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
+                   "frac": round(tflops / peak, 4), "traffic": None, "kernel": kname,
+                   "kernel_ms": round(trunk_ms, 4), "flop_per_board": SPLIT_FLOP_PER_BOARD if split else TRUNK_FLOP_PER_BOARD,
+                   "boards_per_launch": nb, "algorithmic_tflops": round(algo_tflops, 2),
+                   "algorithmic_flop_per_board": TRUNK_FLOP_PER_BOARD,
+                   # three f16 products per multiply are part of the method, the padding of K from 144 to 160 is not:
+                   "frac_without_k_padding": round(SPLIT_NOPAD_FLOP_PER_BOARD * nb / (trunk_ms * 1e-3) / 1e12 / peak, 4) if split else None,
+                   "note": ("f16 matrix instructions on split fp32 operands (a = hi + lo / 2^11; 3 products per multiply, K 144 -> 160): "
+                            "the algorithmic rate is %.2f x the fp32 matrix peak of %.1f TFLOP/s that bounded round 1's tower; "
+                            "kernel_ms = one launch over ALL boards of a slot group, timed alone after the run -- inside a tick the "
+                            "tower skips the boards whose output is cached (about half: tick_kernels.tower_ms)"
+                            % (algo_tflops / MFMA_F32_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS)) if split else "fp32 matrix instructions"}
+    roofline, second, tick_kernels = tower_block, None, None
+    if tk is not None:
+        tower_tick_ms, search_ms, slots = tk
+        tick_kernels = {"slots_per_launch": slots, "tower_ms": round(tower_tick_ms, 4), "k_expand_select_ms": round(search_ms, 4),
+                        "how": "HIP events on the slot group's stream, eager launches after the timed region, other group idle; medians"}
+        pm = load_pmc("r03_mcts_pmc.json")
+        search_bytes = SIM_BYTES * slots
+        gbs = search_bytes / (search_ms * 1e-3) / 1e9
+        search_block = {"bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 6), "traffic": None, "kernel": "k_expand_select",
+                        "kernel_ms": round(search_ms, 4), "simulations_per_launch": slots,
+                        "algorithmic_bytes_per_simulation": SIM_BYTES, "survey_bytes_per_simulation": SIM_BYTES_SURVEY,
+                        "note": "one workgroup per slot walking a dependent chain (selection, make_move, legal-move search, heads, "
+                                "backup): latency-bound, neither HBM nor issue binds; the HBM fraction is nominal (SURVEY 8d). "
+                                "Algorithmic bytes: DESIGN.md 3.3 (the 46 KB policy row of SURVEY's 54 KB is fused away)"}
+        if pm and pm.get("kernel") == "k_expand_select":
+            scale = slots / float(pm["slots_per_launch"])
+            search_block["traffic"] = int((pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]) * scale)
+            search_block["counters"] = {k: pm[k] for k in ("wait_any_frac", "l2_hit_rate", "valu_inst_per_wave", "vmem_rd_per_wave",
+                                                           "fetch_bytes_per_launch", "write_bytes_per_launch", "slots_per_launch",
+                                                           "source") if k in pm}
+        # the block named "roofline" is the kernel with the larger share of the tick
+        if search_ms >= tower_tick_ms:
+            roofline, second = search_block, ("roofline_tower", tower_block)
+        else:
+            second = ("roofline_search", search_block)
+    out = {
         "metric": "MCTS moves/sec at MAX_ITER=160 (GPU search + AlphaSame(10,16) fp32)",
         "value": round(moves_total / elapsed, 1), "unit": "moves/s",
         "simulations_per_sec": round(sims_total / elapsed, 1),
@@ -166,17 +210,15 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
                    "simulations_timed": sims_total, "slot_groups": groups,
                    "records_to_rank0_mb": round(gathered / 1e6, 1),
                    "parallelism": "games sharded by rank; move records gathered to rank 0 (dist.gather, GPU to GPU) in the timed region"},
-        "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
-                     "frac": round(tflops / peak, 4), "traffic": None, "kernel": kname,
-                     "kernel_ms": round(trunk_ms, 4), "flop_per_board": SPLIT_FLOP_PER_BOARD if split else TRUNK_FLOP_PER_BOARD,
-                     "boards_per_launch": nb, "algorithmic_tflops": round(algo_tflops, 2),
-                     "algorithmic_flop_per_board": TRUNK_FLOP_PER_BOARD,
-                     "note": ("f16 matrix instructions on split fp32 operands (a = hi + lo / 2^11; 3 products per multiply, K 144 -> 160): "
-                              "the algorithmic rate is %.2f x the fp32 matrix peak of %.1f TFLOP/s that bounded round 1's tower; "
-                              "kernel_ms = one launch over ALL boards of a slot group, timed alone after the run -- inside a tick the "
-                              "tower skips the boards whose output is cached (about half: the kernel-trace average is about half of this)"
-                              % (algo_tflops / MFMA_F32_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS)) if split else "fp32 matrix instructions"},
+        "roofline": roofline,
     }
+    if second is not None:
+        out[second[0]] = second[1]
+    if tick_kernels is not None:
+        out["tick_kernels"] = tick_kernels
+    if per_rank is not None:
+        out["per_rank_value"] = per_rank
+    return out
 
 
 WIDE_FLOP_PER_BOARD = 2 * 400 * (25 * 64 + 40 * 576 * 64 + 64)      # C5 tower: conv5x5 + 40 conv3x3 (64 ch) + conv1x1 = 1.18 GFLOP
@@ -213,16 +255,16 @@ def bench_c5(args, rank, local_rank, world, dist, dev, barrier):
     barrier()
     elapsed = time.perf_counter() - t0
     st1 = sp.stats()
-    if st1["overflow"] or st1["records_dropped"]:
-        raise SystemExit("tree / record capacity overflowed during the C5 benchmark: results invalid")
+    if st1["overflow"] or st1["records_dropped"] or st1.get("tower_overflow"):
+        raise SystemExit("tree / record capacity (or the split towers' activation range) overflowed during the C5 benchmark: results invalid")
     boards = sp.grids.reshape(2 * n, 1, 40, 10)
     with torch.cuda.stream(sp.stream):
-        sp.net.trunk(boards)
+        sp.net._trunk_hip(boards, sp.net._folded["packed_tower"])       # the launch alone (trunk() also waits and reads the range guard)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 5
         e0.record(sp.stream)
         for _ in range(reps):
-            sp.net.trunk(boards)
+            sp.net._trunk_hip(boards, sp.net._folded["packed_tower"])       # the launch alone (trunk() also waits and reads the range guard)
         e1.record(sp.stream)
     e1.synchronize()
     trunk_ms = e0.elapsed_time(e1) / reps
@@ -254,9 +296,9 @@ def bench_c5(args, rank, local_rank, world, dist, dev, barrier):
     }
 
 
-def cpu_baseline_mcts(seconds_target=12.0):
-    """oracle search (C) + the stub evaluator is not the C3 workload; the honest CPU statement of C3 is
-    the oracle's play_game with the same net on PyTorch-CPU.  One game slot, one thread, bounded sample."""
+def cpu_baseline_mcts(seconds_target=12.0, blocks=10, filters=16, max_iter=160, forced=False):
+    """oracle search (C) + the stub evaluator is not the C3 / C5 workload; the honest CPU statement of it is
+    the oracle's search with the same net on PyTorch-CPU.  One game slot, one thread, bounded sample."""
     import ctypes as C
     import numpy as np
     import torch
@@ -264,12 +306,17 @@ def cpu_baseline_mcts(seconds_target=12.0):
     import oracle_py as op
     import tetris_rl_amd as trl
     torch.manual_seed(0)
-    net = trl.AlphaSame(trl.AlphaSameConfig(blocks=10, filters=16)).prepare()
+    net = trl.AlphaSame(trl.AlphaSameConfig(blocks=blocks, filters=filters)).prepare()
     torch.set_num_threads(1)
     L = op.lib()
     EVAL = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p)
     state = np.zeros(320, dtype=np.uint8)
     from tetris_rl_amd import records
+    t0 = time.perf_counter()
+    evals = [0]
+
+    class Done(Exception):
+        pass
 
     def ev(gptr, vptr, pptr, ctx):
         L.to_export(gptr, state.ctypes.data)
@@ -279,15 +326,16 @@ def cpu_baseline_mcts(seconds_target=12.0):
         v, p = net.evaluate_packed(torch.from_numpy(grids), torch.from_numpy(vec))
         vptr[0] = float(v[0])
         C.memmove(pptr, p.numpy().ctypes.data, 11583 * 4)
+        evals[0] += 1
 
     cb = EVAL(ev)
     L.to_mcts.argtypes = [C.c_void_p, C.POINTER(op.MctsConfig), EVAL, C.c_void_p, C.POINTER(op.MctsResult)]
     g = op.OracleGame(ruleset=2, seed=SEED, stream=0)
-    cfg = op.default_mcts_config(max_iter=160, training=1)
+    cfg = op.default_mcts_config(max_iter=max_iter, training=1, use_forced=int(bool(forced)))
     res = op.MctsResult()
-    t0 = time.perf_counter()
     moves = sims = 0
-    while time.perf_counter() - t0 < seconds_target and not g.is_terminal():
+    # whole searches only (a search cannot be cut short through the oracle's interface): at least one, then until the time is up
+    while (moves == 0 or time.perf_counter() - t0 < seconds_target) and not g.is_terminal():
         L.to_mcts(g._buf, C.byref(cfg), cb, None, C.byref(res))
         g.make_move(res.move)
         moves += 1
@@ -295,8 +343,8 @@ def cpu_baseline_mcts(seconds_target=12.0):
     dt = time.perf_counter() - t0
     return {"value": round(moves / dt, 3), "unit": "moves/s", "cores": 1, "kind": "port",
             "simulations_per_sec": round(sims / dt, 1),
-            "sample": "oracle search (C) + same AlphaSame(10,16) on PyTorch-CPU 1 thread, game stream 0, %d moves / %d simulations in %.1f s"
-                      % (moves, sims, dt)}
+            "sample": "oracle search (C) + same AlphaSame(%d,%d) on PyTorch-CPU 1 thread, game stream 0, %d moves / %d simulations in %.1f s"
+                      % (blocks, filters, moves, sims, dt)}
 
 
 def load_pmc(name="r02_env_rollout_pmc.json"):
@@ -318,27 +366,61 @@ def cpu_shard(c, per):
     print(ob.rollout_random(1000))
 
 
-def launch_ranks(n, argv):
+def _end_process_groups(procs, grace=10.0):
+    """terminate exactly the rank processes started here (each leads its own session, so its helpers go with it)"""
+    import signal
+    import subprocess
+    alive = [p for p in procs if p.poll() is None]
+    for p in alive:
+        try:
+            os.killpg(p.pid, signal.SIGTERM)
+        except (ProcessLookupError, PermissionError):
+            pass
+    deadline = time.monotonic() + grace
+    for p in alive:
+        try:
+            p.wait(timeout=max(0.1, deadline - time.monotonic()))
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+            p.wait()
+
+
+def launch_ranks(n, argv, rank_timeout):
     """`python bench.py --gpus N` started as ONE process: this parent makes no GPU call; it starts N fresh rank processes
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would set them), relays rank 0's JSON line and
-    exits non-zero if any rank does."""
+    exits non-zero if any rank does -- or if the ranks are not done after `rank_timeout` seconds (a rank parked in a
+    collective, the failure a first RCCL run produces): then it says which ranks were still alive, ends them and exits 124.
+    The same clean-up runs when this process is told to stop (SIGTERM / SIGINT from a caller's own timeout)."""
+    import signal
     import socket
     import subprocess
+    import tempfile
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    import tempfile
     fd, line_path = tempfile.mkstemp(prefix="trl_bench_", suffix=".json")
     os.close(fd)
     procs, rc = [], 0
-    for r in range(n):
-        # rank 0 writes the JSON line to TRL_BENCH_JSON; the ranks' stdout (gloo / RCCL banners) goes to stderr, so
-        # this process prints the ONE line and nothing else
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TRL_BENCH_JSON=line_path)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=sys.stderr))
+
+    def stop(signum, frame):
+        sys.stderr.write("bench.py: signal %d: ending the rank processes\n" % signum)
+        _end_process_groups(procs)
+        os._exit(128 + signum)
+
+    old_handlers = {sg: signal.signal(sg, stop) for sg in (signal.SIGTERM, signal.SIGINT)}
+    t_start = time.monotonic()
     try:
+        for r in range(n):
+            # rank 0 writes the JSON line to TRL_BENCH_JSON; the ranks' stdout (gloo / RCCL banners) goes to stderr, so
+            # this process prints the ONE line and nothing else
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TRL_BENCH_JSON=line_path)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=sys.stderr,
+                                          start_new_session=True))
         pending = list(procs)
         while pending and not rc:
             for p in list(pending):
@@ -346,16 +428,16 @@ def launch_ranks(n, argv):
                 if code is not None:
                     pending.remove(p)
                     rc = rc or code
+            if pending and not rc and time.monotonic() - t_start > rank_timeout:
+                alive = [procs.index(p) for p in pending]
+                sys.stderr.write("bench.py: ranks %s still running after --rank-timeout %.0f s (ranks %s had finished): "
+                                 "ending them\n" % (alive, rank_timeout, [r for r in range(n) if r not in alive]))
+                rc = 124
             time.sleep(0.05)
     finally:
-        for p in procs:                                     # a failed rank leaves the others inside a collective:
-            if p.poll() is None:                            # end exactly the processes started here
-                p.terminate()
-                try:
-                    p.wait(timeout=30)
-                except subprocess.TimeoutExpired:
-                    p.kill()
-                    p.wait()
+        _end_process_groups(procs)                          # a failed rank leaves the others inside a collective
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
     with open(line_path) as f:
         line = f.read()
     os.unlink(line_path)
@@ -366,6 +448,79 @@ def launch_ranks(n, argv):
     sys.stdout.flush()
 
 
+def arm_watchdog(seconds, rank):
+    """a rank started by torch.distributed.run has no parent of ours to end it: a daemon timer ends a rank that is still
+    running after --rank-timeout (a wait inside a collective releases the GIL, so the timer does fire)"""
+    import threading
+
+    def fire():
+        sys.stderr.write("bench.py: rank %d still running after --rank-timeout %.0f s: exiting\n" % (rank, seconds))
+        sys.stderr.flush()
+        os._exit(124)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def bench_c1(args, local_rank):
+    """BASELINE config C1, the reference's own case (simulation.py: one self-play game, ruleset s2, AlphaSame(10,16),
+    MAX_ITER=160, training=True) through the package's play_game path on ONE slot.  One slot leaves the chip idle; it is the
+    configuration the CPU reference is quoted on, so it is reported, not optimised for."""
+    import numpy as np
+    import torch
+    import tetris_rl_amd as trl
+    from tetris_rl_amd import selfplay
+    torch.manual_seed(0)
+    mc = trl.AlphaSameConfig(blocks=10, filters=16)
+    net = trl.AlphaSame(mc)
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=160, training=True)
+    selfplay._run_games(cfg, net, 1, SEED, device=local_rank, streams=np.array([1], dtype=np.uint32))     # warm-up: library, graph capture
+    moves = 0
+    t0 = time.perf_counter()
+    for k in (2, 3):
+        games, _ = selfplay._run_games(cfg, net, 1, SEED, device=local_rank, streams=np.array([k], dtype=np.uint32))
+        moves += len(games[0]["moves"])
+    dt = time.perf_counter() - t0
+    return {"metric": "MCTS moves/sec, one self-play game at a time (C1)", "value": round(moves / dt, 2), "unit": "moves/s",
+            "config": {"workload": "C1: single self-play game (1 slot), ruleset s2, AlphaSame blocks=10 filters=16, MAX_ITER=160, "
+                                   "training=True; 2 games back to back through _run_games (engine set-up and graph capture of each "
+                                   "game inside the timed region)", "games": 2, "moves_timed": moves},
+            "note": "Python reference on one core of the build container: 0.77 moves/s (SURVEY section 6)"}
+
+
+def time_tick_kernels(sp, reps=48):
+    """HIP events around the two launches of the production tick (tower on the flagged boards, k_expand_select), issued
+    eagerly on the slot group's own stream after the timed region -- the other group idle, so each kernel has the chip to
+    itself.  Returns (tower ms, search ms, slots) as medians, or None when the tick is not the fused native one."""
+    import statistics
+    part = getattr(sp, "parts", [sp])[0]
+    if not getattr(part, "fused_select", False):
+        return None
+    torch = part.torch
+    for p in getattr(sp, "parts", [sp]):
+        p.synchronize()
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(reps)]
+    with torch.cuda.stream(part.stream):
+        for e0, e1, e2 in ev:
+            e0.record(part.stream)
+            part.net.tower_need(part.grids, part.need, out=part.z)
+            e1.record(part.stream)
+            part.engine.mcts_expand_alphasame_select(part.z.data_ptr(), part.vec.data_ptr(), part.heads, part.grids.data_ptr(),
+                                                     part.need.data_ptr())
+            e2.record(part.stream)
+    part.synchronize()
+    part.ticks += reps
+    tower = statistics.median(e0.elapsed_time(e1) for e0, e1, e2 in ev[8:])
+    search = statistics.median(e1.elapsed_time(e2) for e0, e1, e2 in ev[8:])
+    return tower, search, part.n
+
+
+SIM_BYTES = 9500            # DESIGN.md section 3.3: algorithmic bytes of one simulation with the policy row fused away
+SIM_BYTES_SURVEY = 54000    # SURVEY.md section 8(d): the same with the 46 KB softmaxed policy row the reference's data flow reads
+
+
 def main():
     if len(sys.argv) == 4 and sys.argv[1] == "--cpu-shard":
         return cpu_shard(int(sys.argv[2]), int(sys.argv[3]))
@@ -373,6 +528,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--launches", type=int, default=9,
+                    help="timed launches of --steps plies each (every one bracketed by barrier + synchronize); the line "
+                         "reports the median launch, with the minimum and maximum beside it")
     ap.add_argument("--games", type=int, default=GAMES_PER_GPU, help="games per GPU (C2: 4096)")
     ap.add_argument("--preroll", type=int, default=PREROLL_PLIES,
                     help="plies played while the synthetic input is set up, before the warm-up steps: all games start at ply 0 "
@@ -386,23 +544,41 @@ def main():
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 (20x64 net, MAX_ITER=800) measurement")
     ap.add_argument("--c5-ticks", type=int, default=1200, help="timed search ticks of the C5 measurement")
     ap.add_argument("--c5-warmup", type=int, default=50)
+    ap.add_argument("--no-c1", action="store_true", help="skip the C1 (single game) measurement")
+    ap.add_argument("--rank-timeout", type=float, default=300.0,
+                    help="N > 1: seconds after which ranks that are still running are ended and the run fails (exit 124)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and args.gpus > 1:
-        return launch_ranks(args.gpus, sys.argv[1:])        # not under torch.distributed.run: start the ranks here
+        return launch_ranks(args.gpus, sys.argv[1:], args.rank_timeout)   # not under torch.distributed.run: start the ranks here
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1:
+        arm_watchdog(args.rank_timeout, rank)
+        if str(rank) in os.environ.get("TRL_BENCH_TEST_STALL_RANK", "").split(","):     # test hook: this rank never joins the others
+            sys.stderr.write("[bench rank %d] stalling (TRL_BENCH_TEST_STALL_RANK)\n" % rank)
+            sys.stderr.flush()
+            while True:
+                time.sleep(3600)
 
     # CPU baseline legs first, before this process makes its first GPU call (they start one worker process per core)
-    cpu_c2 = cpu_c3 = None
+    cpu_c2 = cpu_c3 = cpu_c5 = None
     if world == 1 and not args.no_cpu_baseline:
         cpu_c2 = cpu_baseline()
         if not args.no_mcts:
             cpu_c3 = cpu_baseline_mcts()
+            if not args.no_c5:
+                # a C5 search is 400 or 2000 evaluations of a 2.4 GFLOP net: minutes per move on one core.  The sample runs
+                # searches of a tenth of the length (MAX_ITER 80: 40 or 200 simulations) with the same net and switches
+                cpu_c5 = cpu_baseline_mcts(seconds_target=10.0, blocks=20, filters=64, max_iter=80, forced=True)
+                cpu_c5["sample"] += "; searches at MAX_ITER=80 instead of 800 (the rate is per simulation: one 20x64 evaluation each)"
+                cpu_c5 = {"value": cpu_c5["simulations_per_sec"], "unit": "simulations/s", "cores": 1, "kind": "port",
+                          "sample": cpu_c5["sample"]}
 
+    import statistics
     import numpy as np
     import torch
     import tetris_rl_amd as trl
@@ -424,11 +600,18 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        sys.stderr.write("[bench rank %d/%d] device_count=%d, bound to cuda:%d (%s), backend=%s, master %s:%s\n"
+                         % (rank, world, ndev, local_rank, torch.cuda.get_device_name(local_rank), backend,
+                            os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")))
+        sys.stderr.flush()
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
         dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size()}     # what the process group saw
+        sys.stderr.write("[bench rank %d/%d] process group up: backend %s, world size %d\n"
+                         % (rank, world, dist_info["backend"], dist_info["world_size"]))
+        sys.stderr.flush()
 
     n = args.games
     eng = trl.Engine(n, ruleset="s2", seed=SEED, device=local_rank)
@@ -443,23 +626,39 @@ def main():
 
     if args.warmup > 0:
         eng.rollout_random(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    steps_done = eng.rollout_random(args.steps)          # one launch, K plies of every game; syncs its stream
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = eng.last_kernel_ms()                      # HIP events on the engine's stream
+    # R timed launches of K plies each (1 step = 1 ply of every game; a launch = --steps plies), every launch bracketed
+    # by barrier + synchronize on both sides and reduced over the ranks (max time, total steps): the line reports the
+    # MEDIAN launch -- one 0.8 ms launch is one sample of a quantity that spreads by a few per cent
+    launches = []
+    for _ in range(max(1, args.launches)):
+        barrier()
+        t0 = time.perf_counter()
+        steps_done = eng.rollout_random(args.steps)          # one launch, K plies of every game; syncs its stream
+        torch.cuda.synchronize()
+        barrier()
+        wall = time.perf_counter() - t0
+        kms = eng.last_kernel_ms()                           # HIP events on the engine's stream
+        wall_job, steps_job = parallel.reduce_job(wall, steps_done, dist, dev)
+        kms_job, _ = parallel.reduce_job(kms, 0, dist, dev)
+        launches.append({"wall": wall_job, "steps": steps_job, "kernel_ms": kms_job, "my_wall": wall, "my_steps": steps_done})
+    order = sorted(range(len(launches)), key=lambda i: launches[i]["steps"] / launches[i]["wall"])
+    med = launches[order[len(order) // 2]]
+    elapsed, steps_total, kernel_ms = med["wall"], med["steps"], med["kernel_ms"]
+    rates = [l["steps"] / l["wall"] for l in launches]
+    per_rank = None
+    if dist is not None:                                      # every rank's own rate of the median launch, for the SCALE check
+        pr = parallel.all_gather_ints([int(med["my_steps"]), int(med["my_wall"] * 1e9)], dist, dev)
+        per_rank = [round(float(a) / (float(b) * 1e-9), 1) for a, b in pr]
 
     flags = eng.get_state()[:, 313]
     if (flags & 3).any():
         raise SystemExit("a cap overflowed during the benchmark: results invalid")
+    stream_wrap = bool((flags & 4).any())                     # TRL_FLAG_STREAM_WRAP: a slot went through 256 episodes
 
-    elapsed, steps_total = parallel.reduce_job(elapsed, steps_done, dist, dev)
-    kernel_ms, _ = parallel.reduce_job(kernel_ms, 0, dist, dev)
     eng.close()
     mcts = None if args.no_mcts else bench_mcts(args, rank, local_rank, world, dist, dev, barrier)
     c5 = None if (args.no_mcts or args.no_c5) else bench_c5(args, rank, local_rank, world, dist, dev, barrier)
+    c1 = None if (args.no_mcts or args.no_c1 or world > 1) else bench_c1(args, local_rank)
 
     if rank == 0:
         value = steps_total / elapsed
@@ -470,9 +669,9 @@ def main():
         if pmc and pmc.get("games") == n:
             # HBM-side bytes of one launch: the committed per-ply counter figures scaled to this launch's length
             traffic = int(pmc["hbm_bytes_fixed_per_launch"] + pmc["hbm_bytes_per_ply"] * args.steps)
-            # the bound that binds: vector-instruction issue.  2 waves per game, every wave64 vector instruction holds
-            # its SIMD for VALU_ISSUE_CYCLES cycles (measured, scripts/valu_peak.hip)
-            inst = pmc["valu_inst_per_wave_ply"] * 2 * n * args.steps
+            # the bound that binds: vector-instruction issue.  every wave64 vector instruction holds its SIMD for
+            # VALU_ISSUE_CYCLES cycles (measured, scripts/valu_peak.hip)
+            inst = pmc["valu_inst_per_wave_ply"] * pmc.get("waves_per_game", 2) * n * args.steps
             rate = inst / (kernel_ms * 1e-3)
             peak = pmc["simds"] * pmc["clock_ghz"] * 1e9 / pmc["valu_issue_cycles"]
             valu = {"bound": "valu_issue", "achieved": round(rate / 1e9, 2), "peak": round(peak / 1e9, 2),
@@ -495,6 +694,9 @@ def main():
                                    "policy, auto-reset on terminal; 1 step = 1 ply of every game" % n,
                        "games_per_gpu": n, "seed": SEED, "plies_timed": args.steps, "preroll_plies": args.preroll,
                        "env_steps_timed": steps_total, "parallelism": "games sharded by rank, no collective"},
+            "launches": {"n": len(launches), "plies_per_launch": args.steps, "reported": "median launch",
+                         "value_min": round(min(rates), 1), "value_max": round(max(rates), 1),
+                         "values": [round(r, 1) for r in rates]},
             "dist": dist_info,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 8), "traffic": traffic,
@@ -502,12 +704,20 @@ def main():
                          "algorithmic_bytes_per_step": BYTES_PER_STEP,
                          "note": "integer/latency-bound search; HBM is nominal (SURVEY 8d); the binding bound is roofline_valu"},
         }
+        if per_rank is not None:
+            out["per_rank_value"] = per_rank
+        if stream_wrap:
+            out["config"]["stream_wrap"] = "a slot passed 256 episodes and replays its first games (TRL_FLAG_STREAM_WRAP)"
         if valu is not None:
             out["roofline_valu"] = valu
         if mcts is not None:
             out["mcts"] = mcts
         if c5 is not None:
             out["mcts_c5"] = c5
+            if cpu_c5 is not None:
+                out["mcts_c5"]["cpu_baseline"] = cpu_c5
+        if c1 is not None:
+            out["c1"] = c1
         if cpu_c2 is not None:
             out["cpu_baseline"] = cpu_c2
             if mcts is not None and cpu_c3 is not None:

@@ -91,6 +91,8 @@ typedef struct trl_player_state {
 
 #define TRL_FLAG_OVERFLOW   1u   /* a cap was exceeded in this game; its state is not trustworthy */
 #define TRL_FLAG_BADMOVE    2u   /* env_step was given a move that is not legal in this state      */
+#define TRL_FLAG_STREAM_WRAP 4u  /* rollout mode: this slot has been set up again 256 times -- episode e runs on RNG    */
+                                 /* stream + e * 2^24 (uint32), so from here on it replays the games of its first episodes */
 
 typedef struct trl_game_state {
     trl_player_state p[2];    /* p[0] = Human/colour 0 moves first, p[1] = AI/colour 1 (player.py:253-261) */
@@ -402,6 +404,14 @@ int  trl_alphasame_trunk(const float *dev_boards, int n_boards, const float *dev
  * b1[F] W1 b2[F] W2 (3x3 convs packed as for trl_alphasame_trunk); tail Wk[kout][F]; >= 16 KiB of padding. */
 int  trl_resnet_trunk(const float *dev_boards, int n_boards, const float *dev_packed, int filters, int n_blocks, int kout,
                       float *dev_out, const uint8_t *dev_need, void *stream);
+
+/* Range guard of the split towers (trl_alphasame_trunk16_split, trl_trunk_wide_split).  They split every activation into
+ * two f16 halves; an activation of 65 504 or more has no finite hi half and the board's output would be built on inf / NaN
+ * (the folded conv WEIGHTS are range-checked on the host when they are packed, activations can only be checked here).
+ * *count_out = boards, since the last reset, in which that happened on HIP device `device`; reset != 0 clears the count.
+ * The caller synchronises the stream(s) its towers ran on first.  A caller that sees a count > 0 runs those boards again
+ * on the fp32 towers (trl_alphasame_trunk / trl_resnet_trunk), which have no such limit -- nets.AlphaSame.trunk() does.    */
+int  trl_tower_overflow(int device, int reset, uint32_t *count_out);
 
 #ifdef __cplusplus
 }

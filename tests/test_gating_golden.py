@@ -49,9 +49,16 @@ def test_tallies_match_reference(golden_dir):
         assert i == 7 and acc is False and w.tolist() == [3, 4]
 
 
-def test_draw_in_the_sequential_form_raises_like_the_reference():
-    """ai.py:1991 / 2022: integer win counters and `wins += 0.5` for a draw -- numpy refuses the in-place cast"""
-    import pytest
-    with pytest.raises(TypeError):
-        gating.scan_sequential(np.zeros(2, dtype=int), [-1], 0, 4, 0.5, "more")
+def test_draw_in_the_sequential_form_counts_half_a_point():
+    """ai.py:1991 / 2022: the reference keeps integer win counters and does `wins += 0.5` for a draw, which numpy refuses
+    (UFuncTypeError) -- inside self_play_loop that would abort the loop after the set was generated and the challenger
+    trained.  battle_networks here scans with a float array: a draw is half a point each, and the result is the
+    reference's integer array whenever no game was drawn."""
+    w = np.zeros(2, dtype=float)
+    n, acc = gating.scan_sequential(w, [-1, 0, 1, -1], 0, 8, None, "more")
+    assert n == 4 and acc is None and w.tolist() == [1.0, 3.0]          # game 1: colours flipped -> network 2 wins it
+    assert gating._as_reference_wins(w).dtype.kind == "i"
+    w = np.zeros(2, dtype=float)
+    gating.scan_sequential(w, [-1, 0], 0, 8, None, "more")
+    assert gating._as_reference_wins(w).tolist() == [0.5, 1.5]
     assert gating.tally_concurrent([-1, 0, 1]).tolist() == [0.5, 2.5]   # the concurrent form counts halves (game 1: colours flipped)

@@ -135,3 +135,27 @@ def test_native_two_network_tick():
     assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
     same_first = sum(runs[0][1][g][0] == runs[2][1][g][0] for g in range(games))
     assert same_first >= games - 2
+
+
+def test_gating_and_single_searches_never_open_with_random_moves():
+    """Config.use_random_starting_moves is play_game's (ai.py:1588-1608): battle_networks and MCTS() search from ply 0
+    (ai.py:2012-2014).  With the flag on, no record of a match is a random move and every first move has a full search
+    behind it."""
+    cfg = trl.Config(visual=False, model="pytorch", MAX_ITER=12, training=False, use_random_starting_moves=True)
+    b = gating.Battle(cfg, StubEval(SALT1), StubEval(SALT2), 6, seed=5)
+    e = b.engine
+    b.tick(12)
+    b.stream.synchronize()
+    r = e.mcts_drain_records()
+    r = r[r["kind"] == trl.REC_MOVE]
+    assert len(r) == 6 and not r["random_move"].any()
+    nch = r["n_children"].astype(np.int64)
+    assert all(int(m["visits"][:k].sum()) == 11 for m, k in zip(r, nch))          # 12 simulations, not a one-simulation pick
+    # the same games as with the flag off
+    cfg0 = cfg.copy(); cfg0.use_random_starting_moves = False
+    b0 = gating.Battle(cfg0, StubEval(SALT1), StubEval(SALT2), 6, seed=5)
+    b0.tick(12)
+    b0.stream.synchronize()
+    r0 = b0.engine.mcts_drain_records()
+    r0 = r0[r0["kind"] == trl.REC_MOVE]
+    assert np.array_equal(np.sort(r["chosen"]), np.sort(r0["chosen"]))

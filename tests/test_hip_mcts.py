@@ -405,3 +405,30 @@ def test_search_limits_are_refused():
     with pytest.raises(trl.EngineError):
         eng.mcts_create(trl.mcts_config(max_iter=8, episodes_base=300))
     eng.mcts_create(trl.mcts_config(max_iter=8, episodes_base=2, episodes_extra=1))
+
+
+def test_a_quota_of_exactly_256_games_ends_cleanly():
+    """episode e of a slot runs on RNG stream + e * 2^24 (uint32): 256 episodes per slot are the most a quota may ask for,
+    and a slot that finishes its 256th game on that quota stops without tripping the stream-wrap guard (the guard is for
+    slots that would go ON); without a quota the same slot is stopped and counted as an overflow"""
+    for quota, want_overflow in ((256, 0), (0, 1)):
+        eng = trl.Engine(2, ruleset="s2", seed=4242)
+        eng.reset()
+        st = eng.get_state()
+        st[:, 308:312] = np.frombuffer(np.uint32(254).tobytes(), dtype=np.uint8)     # trl_game_state.episode: two games to go
+        eng.set_state(st)
+        s = StubSearch(eng, trl.mcts_config(max_iter=4, training=0, auto_reset=1, episodes_base=quota, episodes_extra=0))
+        ends = []
+        for t in range(60000):
+            s.tick()
+            if t % 128 == 127:
+                r = eng.mcts_drain_records()
+                ends += [int(e) for e in r["episode"][r["kind"] == trl.REC_GAME_END]]
+                if len(ends) >= 4:
+                    break
+        for _ in range(8):
+            s.tick()                                   # idle slots stay idle
+        stats = eng.mcts_stats()
+        assert sorted(ends) == [254, 254, 255, 255], ends
+        assert stats["games"] == 4 and bool(stats["overflow"]) == bool(want_overflow), (quota, stats)
+        eng.close()

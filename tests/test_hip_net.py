@@ -9,9 +9,19 @@ import torch
 
 import tetris_rl_amd as trl
 from tetris_rl_amd import records
-from test_net_parity import load_net, packed_features, load_formula_net, DEEP, TOL
+from test_net_parity import load_net, packed_features, load_formula_net, DEEP, TOL, NET64, load_net64, check_net64, scaled_copy
 
 pytestmark = pytest.mark.gpu
+
+# both tower implementations ship (nets.tower_mode): "split" = k_trunk16s / k_trunk_wide_s (the default), "fp32" =
+# k_trunk16 / k_trunk_wide (TRL_TOWER=fp32, and the fallback for weights or activations outside the split kernels' range)
+TOWER_MODES = ("split", "fp32")
+
+
+def _set_mode(net, mode):
+    net.tower_mode = mode
+    assert net._folded["packed_tower"] is not None and (mode == "fp32" or net._folded["packed_split"] is not None)
+    return net
 
 
 def test_kernel_features_match_game_to_x(golden_dir):
@@ -41,10 +51,15 @@ def test_kernel_features_match_game_to_x(golden_dir):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("mode", TOWER_MODES)
 @pytest.mark.parametrize("tag,blocks,filters", [("b10f16", 10, 16), ("b2f8", 2, 8)])
-def test_net_on_device_matches_reference(golden_dir, tag, blocks, filters):
+def test_net_on_device_matches_reference(golden_dir, tag, blocks, filters, mode):
     d = np.load(os.path.join(golden_dir, "net.npz"))
     net = load_net(d, tag, blocks, filters, device="cuda")
+    if filters == 16:
+        _set_mode(net, mode)
+    elif mode == "fp32":
+        pytest.skip("8 filters: no fused tower, one PyTorch path")
     grids, vec = packed_features(d["states"])
     v, logits = net.heads(torch.from_numpy(grids).cuda(), torch.from_numpy(vec).cuda())
     assert np.abs(torch.sigmoid(v).cpu().numpy() - d["%s/values" % tag]).max() < TOL
@@ -209,13 +224,13 @@ def test_self_play_loop_with_the_default_net_family(tmp_path, monkeypatch):
     assert len(log) == 1 and "aux_loss" in log[0]
 
 
-def test_fused_hip_tower_matches_torch_tower(golden_dir):
-    """csrc/trl_net.hip (fp32 MFMA, activations in LDS) against the same tower as PyTorch ops, on
-    random occupancy boards incl. full, empty and checkerboard ones; fp32 tolerance 2e-5 absolute on
-    outputs of magnitude ~1 (different summation order only)."""
+@pytest.mark.parametrize("mode", TOWER_MODES)
+def test_fused_hip_tower_matches_torch_tower(golden_dir, mode):
+    """csrc/trl_net.hip -- k_trunk16s (split f16 operands, the default) and k_trunk16 (fp32 MFMA), activations in LDS --
+    against the same tower as PyTorch ops, on random occupancy boards incl. full, empty and checkerboard ones; fp32
+    tolerance 2e-5 absolute on outputs of magnitude ~1 (different summation order only)."""
     d = np.load(os.path.join(golden_dir, "net.npz"))
-    net = load_net(d, "b10f16", 10, 16, device="cuda")
-    assert net._folded["packed_tower"] is not None
+    net = _set_mode(load_net(d, "b10f16", 10, 16, device="cuda"), mode)
     g = torch.Generator().manual_seed(3)
     m = 515
     boards = (torch.rand((m, 1, 40, 10), generator=g) < torch.rand((m, 1, 1, 1), generator=g)).float()
@@ -232,13 +247,14 @@ def test_fused_hip_tower_matches_torch_tower(golden_dir):
     assert float(b.abs().max()) > 0.01
 
 
+@pytest.mark.parametrize("mode", TOWER_MODES)
 @pytest.mark.parametrize("tag,blocks,filters", [("b3f64", 3, 64), ("b2f32", 2, 32)])
-def test_wide_fused_tower(golden_dir, tag, blocks, filters):
-    """k_trunk_wide<32/64>: (1) the reference's logits and values of the fixture positions within 1e-5 through
-    the HIP tower, (2) against the PyTorch tower on random boards, (3) the need flags skip boards"""
+def test_wide_fused_tower(golden_dir, tag, blocks, filters, mode):
+    """k_trunk_wide_s<32/64> (split) and k_trunk_wide<32/64> (fp32): (1) the reference's logits and values of the fixture
+    positions within 1e-5 through the HIP tower, (2) against the PyTorch tower on random boards, (3) the need flags skip boards"""
     d = np.load(os.path.join(golden_dir, "net_wide.npz"))
-    net = load_net(d, tag, blocks, filters, device="cuda")
-    assert net._folded["packed_tower"] is not None and net.supports_tower_cache
+    net = _set_mode(load_net(d, tag, blocks, filters, device="cuda"), mode)
+    assert net.supports_tower_cache
     grids, vec = packed_features(d["states"])
     v, logits = net.heads(torch.from_numpy(grids).cuda(), torch.from_numpy(vec).cuda())
     assert np.abs(torch.sigmoid(v).cpu().numpy() - d["%s/values" % tag]).max() < TOL
@@ -258,14 +274,15 @@ def test_wide_fused_tower(golden_dir, tag, blocks, filters):
     assert torch.equal(c[need.bool()], a[need.bool()]) and not c[~need.bool()].any()
 
 
+@pytest.mark.parametrize("mode", TOWER_MODES)
 @pytest.mark.parametrize("tag", sorted(DEEP))
-def test_deep_and_tanh_nets_on_device(golden_dir, tag):
-    """C5's net at its full depth on k_trunk_wide<64> (40 convolutions, K = 576, fp32 MFMA accumulation) and the tanh
-    value head on k_trunk16: the reference's values and all 11 583 logits within 1e-5"""
+def test_deep_and_tanh_nets_on_device(golden_dir, tag, mode):
+    """C5's net at its full depth on k_trunk_wide_s<64> / k_trunk_wide<64> (40 convolutions, K = 576) and the tanh
+    value head on k_trunk16s / k_trunk16: the reference's values and all 11 583 logits within 1e-5"""
     blocks, filters, salt, use_tanh = DEEP[tag]
     d = np.load(os.path.join(golden_dir, "net_deep.npz"))
-    net = load_formula_net(blocks, filters, salt, use_tanh, device="cuda")
-    assert net._folded["packed_tower"] is not None and net.use_hip_trunk
+    net = _set_mode(load_formula_net(blocks, filters, salt, use_tanh, device="cuda"), mode)
+    assert net.use_hip_trunk
     grids, vec = packed_features(np.load(os.path.join(golden_dir, "net.npz"))["states"])
     v, logits = net.heads(torch.from_numpy(grids).cuda(), torch.from_numpy(vec).cuda())
     v = (torch.tanh(v) if use_tanh else torch.sigmoid(v)).cpu().numpy()
@@ -276,13 +293,14 @@ def test_deep_and_tanh_nets_on_device(golden_dir, tag):
     assert np.abs(lb[-8:].cpu().numpy() - d["%s/logits" % tag]).max() < TOL
 
 
+@pytest.mark.parametrize("mode", TOWER_MODES)
 @pytest.mark.parametrize("tag", ["base32", "aux32"])
-def test_baseresnet_fused_tower(golden_dir, tag):
-    """trl_resnet_trunk (k_trunk_wide<32, POST>): the reference's BaseResNet / AuxBaseResNet outputs within 1e-5
-    through the fused tower, and fused == PyTorch tower on a larger random batch"""
+def test_baseresnet_fused_tower(golden_dir, tag, mode):
+    """k_trunk_wide_s<32, POST> (split) and trl_resnet_trunk's k_trunk_wide<32, POST> (fp32): the reference's BaseResNet /
+    AuxBaseResNet outputs within 1e-5 through the fused tower, and fused == PyTorch tower on a larger random batch"""
     from test_net_parity import load_base32
     d, net = load_base32(golden_dir, tag, device="cuda")
-    assert net._folded["packed_tower"] is not None
+    _set_mode(net, mode)
     grids, vec = packed_features(d["states"])
     tg, tv = torch.from_numpy(grids).cuda(), torch.from_numpy(vec).cuda()
     v, logits = net.heads(tg, tv)
@@ -496,3 +514,169 @@ def test_production_tick_matches_reference_priors(golden_dir):
         assert visits2[g, :counts[g]].sum() == 1 and visits2[g, best] == 1
         checked += 1
     assert checked >= 6
+
+
+# ---- round 3: every shipped tower path at the size it ships at, on positions chosen for the activations' magnitude ----
+@pytest.mark.parametrize("mode", TOWER_MODES)
+@pytest.mark.parametrize("tag", NET64)
+def test_64_positions_on_device(golden_dir, tag, mode):
+    """tests/golden/net64.npz: the reference's value and logits on 64 positions -- tall stacks, garbage-heavy, nearly full
+    and nearly empty boards (the split-f16 scheme's error depends on the activations' magnitude) -- for C3's net, its tanh
+    variant, C5's 20 x 64 net and a 32-filter net, through both tower implementations: within 1e-5"""
+    net, use_tanh = load_net64(golden_dir, tag, device="cuda")
+    _set_mode(net, mode)
+    err = check_net64(golden_dir, tag, net, use_tanh, device="cuda")
+    assert err < TOL
+    assert trl.engine.tower_overflow(0) == 0
+
+
+def test_weights_outside_the_split_range_take_the_fp32_towers(golden_dir):
+    """a net whose folded conv weights reach |w| >= 31 (the split kernels form 2^11 hi_w in f16) must run on the fp32
+    kernels -- said with a RuntimeWarning when the weights are packed -- and meet the same 1e-5: b10f16 with one block
+    rescaled by 2^10 (the same function; powers of two are exact, so the reference's own outputs are net.npz's)"""
+    d = np.load(os.path.join(golden_dir, "net.npz"))
+    base = load_net(d, "b10f16", 10, 16, device="cpu")
+    big = scaled_copy(base, "weight").cuda()
+    with pytest.warns(RuntimeWarning, match="fp32 tower kernels"):
+        big.prepare()
+    fd = big._folded
+    assert fd["packed_tower"] is not None and fd["packed_split"] is None and big.tower_mode == "split"
+    assert float(fd["blocks"][3][2].abs().max()) >= 31.0
+    grids, vec = packed_features(d["states"])
+    v, logits = big.heads(torch.from_numpy(grids).cuda(), torch.from_numpy(vec).cuda())
+    assert np.abs(torch.sigmoid(v).cpu().numpy() - d["b10f16/values"]).max() < TOL
+    assert np.abs(logits.cpu().numpy() - d["b10f16/logits"]).max() < TOL
+    check_net64(golden_dir, "b10f16", big, False, device="cuda")
+    # inside the search: the production tick of such a net is the fp32 kernel (k_trunk16) and plays on
+    cfg = trl.Config(visual=False, model="pytorch", model_config=trl.AlphaSameConfig(blocks=10, filters=16), MAX_ITER=16, training=True)
+    sp = trl.SelfPlay(cfg, big, 32, seed=5)
+    sp.tick(64)
+    st = sp.stats()
+    assert st["simulations"] == 64 * 32 and st["overflow"] == 0 and st["tower_overflow"] == 0
+
+
+def test_activations_outside_the_split_range_are_reported_and_recomputed(golden_dir):
+    """weights < 31 but activations > 65 504 (no finite f16 hi half): the split kernel counts the board
+    (trl_tower_overflow), trunk() warns, switches the net to the fp32 kernels and recomputes -- 1e-5 against the
+    reference either way; inside a captured tick the count shows up in SelfPlay.stats() and make_training_set refuses the
+    set.  b10f16 with block 3's first batch norm x 2^17 and its first conv / 2^17: the same function, bit for bit."""
+    d = np.load(os.path.join(golden_dir, "net.npz"))
+    base = load_net(d, "b10f16", 10, 16, device="cpu")
+    hot = scaled_copy(base, "activation").cuda().prepare()
+    assert hot._folded["packed_split"] is not None and hot.tower_mode == "split"       # the weights fit
+    grids, vec = packed_features(d["states"])
+    tg, tv = torch.from_numpy(grids).cuda(), torch.from_numpy(vec).cuda()
+    # the kernel alone: finite garbage or NaN, and the counter says so
+    trl.engine.tower_overflow(0)
+    hot._trunk_hip(tg.reshape(-1, 1, 40, 10), hot._folded["packed_tower"])
+    torch.cuda.synchronize()
+    assert trl.engine.tower_overflow(0) == 2 * len(d["states"])                       # every board of this net overflows
+    assert trl.engine.tower_overflow(0) == 0                                           # reading resets
+    with pytest.warns(trl.nets.SplitActivationRange):
+        v, logits = hot.heads(tg, tv)
+    assert hot.tower_mode == "fp32"
+    assert np.abs(torch.sigmoid(v).cpu().numpy() - d["b10f16/values"]).max() < TOL
+    assert np.abs(logits.cpu().numpy() - d["b10f16/logits"]).max() < TOL
+    # the captured tick cannot stop to look: the counter is read at the next synchronisation point
+    hot.tower_mode = "split"
+    cfg = trl.Config(visual=False, model="pytorch", model_config=trl.AlphaSameConfig(blocks=10, filters=16), MAX_ITER=16, training=True)
+    sp = trl.SelfPlay(cfg, hot, 16, seed=5)
+    sp.tick(8)
+    assert sp.stats()["tower_overflow"] > 0
+    with pytest.raises(trl.EngineError, match="tower_overflow"):
+        trl.make_training_set(cfg, hot, 4, save_stats=False, seed=1)
+    hot.tower_mode = "fp32"
+    assert len(trl.make_training_set(cfg, hot, 4, save_stats=False, seed=1)) > 0
+
+
+def _sorted_records(sp):
+    r = sp.drain()
+    return r[np.lexsort((r["kind"], r["ply"], r["episode"], r["slot"]))]
+
+
+def test_production_tick_at_c3_size(monkeypatch):
+    """BASELINE config C3 as the bench times it -- 1024 slots, AlphaSame(10, 16) on k_trunk16s, training=True, the fused
+    expand + select launch inside eight-tick graphs, two slot groups on two streams -- for 480 ticks, against the same
+    job run as one group, with the three-kernel tick (TRL_FUSE_SELECT=0) and with one tick per graph (TRL_GRAPH_TICKS=1):
+    identical records, no overflow of any kind, and the invariants of a search (ai.py:299-659) on every record."""
+    from tetris_rl_amd import selfplay
+    torch.manual_seed(0)
+    mc = trl.AlphaSameConfig(blocks=10, filters=16)
+    net = trl.AlphaSame(mc).cuda().prepare()
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=160, training=True)
+    n, ticks, seed = 1024, 480, 20260630
+    out = []
+    for groups, fuse, per_graph in ((2, True, 8), (1, True, 8), (1, False, 8), (1, True, 1)):
+        monkeypatch.setattr(selfplay, "FUSE_SELECT", fuse)
+        monkeypatch.setattr(selfplay, "GRAPH_TICKS", per_graph)
+        kw = dict(seed=seed, auto_reset=True, record_capacity=1 << 15)
+        sp = trl.SelfPlayGroups(cfg, net, n, groups, **kw) if groups > 1 else trl.SelfPlay(cfg, net, n, **kw)
+        part = getattr(sp, "parts", [sp])[0]
+        assert part.fused_select == fuse and part.native_graph and part.heads is not None and part.net.tower_mode == "split"
+        sp.tick(ticks)
+        st = sp.stats()
+        assert st["overflow"] == 0 and st["records_dropped"] == 0 and st["tower_overflow"] == 0
+        assert st["simulations"] == n * ticks
+        out.append((_sorted_records(sp), st))
+        del sp, part
+        torch.cuda.empty_cache()
+    a, sa = out[0]
+    moves = a[a["kind"] == trl.REC_MOVE]
+    assert len(moves) >= 2 * n                                   # every slot finished searches, short and long ones
+    nch = moves["n_children"].astype(np.int64)
+    valid = np.arange(512)[None, :] < nch[:, None]
+    vis = (moves["visits"].astype(np.int64) * valid).sum(axis=1)
+    assert set(np.unique(vis)) <= {399, 79}                      # root children's visits = simulations - 1 (playout cap 400 / 80)
+    assert (moves["saved"] == (vis == 399)).all()                # only the full searches are saved (ai.py:1613)
+    assert ((moves["moves"] == moves["chosen"][:, None]) & valid).any(axis=1).all()      # the move played is a root child
+    for b, sb in out[1:]:
+        assert sb["moves"] == sa["moves"] and sb["games"] == sa["games"] and len(b) == len(a)
+        for f in ("slot", "episode", "ply", "kind", "winner", "chosen", "saved", "n_children", "state"):
+            assert np.array_equal(a[f], b[f]), f
+        va = np.arange(512)[None, :] < a["n_children"][:, None]
+        assert np.array_equal(a["moves"][va], b["moves"][va]) and np.array_equal(a["visits"][va], b["visits"][va])
+
+
+def test_whole_searches_with_the_real_net_match_the_reference(golden_dir):
+    """32 reference searches -- MCTS(config, game, net) at MAX_ITER = 160 with the real 10 x 16 net through
+    evaluate_pytorch (ai.py:299-659, 1296-1319), on tall / garbage-heavy / sparse positions (net64.npz) -- against the
+    production tick (split-f16 tower, tower cache, heads inside the search kernel, fused expand + select).  Logits agree
+    to ~1e-6, but PUCT is an arg-max: where two children's scores are closer than that, one simulation goes to the other
+    child and the subtrees differ from there on.  Stated bar: the same set of root children; the same move wherever the
+    reference's most visited child leads the runner-up by more than 2 visits; and an L1 distance between the visit
+    vectors of at most 16 of the 159 visits in every search, at most 4 on average."""
+    d = np.load(os.path.join(golden_dir, "net64.npz"))
+    pos = d["search_pos"]
+    states = d["states"][pos]
+    n = len(pos)
+    net = load_net(np.load(os.path.join(golden_dir, "net.npz")), "b10f16", 10, 16, device="cuda")
+    cfg = trl.Config(visual=False, model="pytorch", model_config=trl.AlphaSameConfig(blocks=10, filters=16), MAX_ITER=160,
+                     training=False)
+    sp = trl.SelfPlay(cfg, net, n, seed=int(np.load(os.path.join(golden_dir, "env_traces.npz"))["seed"]), auto_reset=False)
+    assert sp.fused_select and sp.native_graph and sp.net.tower_mode == "split"
+    sp.engine.set_state(states)
+    sp.tick(160)
+    st = sp.stats()
+    assert st["tower_overflow"] == 0 and st["overflow"] == 0
+    r = sp.drain()
+    r = r[(r["kind"] == trl.REC_MOVE) & (r["ply"] == np.array([int.from_bytes(bytes(s[300:304]), "little") for s in states])[r["slot"]])]
+    r = r[np.argsort(r["slot"], kind="stable")]
+    assert len(r) == n                                           # every slot's first search is the fixture's
+    off = np.concatenate([[0], np.cumsum(d["search_child_counts"])])
+    l1, decided, same = [], 0, 0
+    for g in range(n):
+        k = int(d["search_child_counts"][g])
+        ref_moves, ref_vis = d["search_child_moves"][off[g]:off[g + 1]], d["search_child_visits"][off[g]:off[g + 1]]
+        assert int(r["n_children"][g]) == k and np.array_equal(r["moves"][g][:k], ref_moves)
+        mine = r["visits"][g][:k].astype(np.int64)
+        assert mine.sum() == ref_vis.sum() == 159
+        l1.append(int(np.abs(mine - ref_vis).sum()))
+        top = np.sort(ref_vis)[::-1]
+        if k == 1 or top[0] - top[1] > 2:
+            decided += 1
+            assert int(r["chosen"][g]) == int(d["search_move"][g]), (g, l1[-1])
+        same += int(r["chosen"][g]) == int(d["search_move"][g])
+    print("real-net searches: L1 visit distance max %d mean %.2f; %d of %d decided searches, %d same moves" %
+          (max(l1), float(np.mean(l1)), decided, n, same))
+    assert decided >= 8
+    assert max(l1) <= 16 and float(np.mean(l1)) <= 4.0

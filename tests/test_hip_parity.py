@@ -275,3 +275,20 @@ def test_device_pointer_entry_points():
     torch.cuda.synchronize()
     ts = torch.as_tensor(_DevView(ps.value, (n, 320), "|u1"), device=dev)
     assert np.array_equal(ts.cpu().numpy(), a.get_state())
+
+
+def test_rollout_says_when_a_slot_runs_out_of_rng_streams():
+    """rollout mode sets a finished game up again on RNG stream + 2^24 (uint32): the 256th re-setup of a slot wraps onto
+    its first stream and the slot replays its games from there -- TRL_FLAG_STREAM_WRAP says so in the state (the search
+    refuses the same condition up front, test_search_limits_are_refused); slots below the limit stay unflagged"""
+    e = trl.Engine(4, ruleset="s2", seed=77)
+    e.reset()
+    st = e.get_state()
+    st[:2, 308:312] = np.frombuffer(np.uint32(254).tobytes(), dtype=np.uint8)       # slots 0, 1: episode 254
+    e.set_state(st)
+    e.rollout_random(3 * 12, max_plies=12)                                           # three games per slot
+    out = e.get_state()
+    episodes = out[:, 308:312].copy().view(np.uint32).reshape(-1)
+    assert (episodes[:2] >= 256).all() and (episodes[2:] < 10).all()
+    assert ((out[:2, 313] & 4) == 4).all() and ((out[2:, 313] & 4) == 0).all()
+    assert not (out[:, 313] & 3).any()

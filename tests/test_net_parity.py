@@ -105,6 +105,63 @@ def test_deep_and_tanh_nets_match_reference(golden_dir, tag):
         assert (d["%s/values" % tag] < 0).any()                 # the fixture does exercise the negative half of the range
 
 
+NET64 = ("b10f16", "b10f16tanh", "b20f64", "b2f32")
+
+
+def load_net64(golden_dir, tag, device="cpu"):
+    """the nets of tests/golden/net64.npz (oracle/gen_golden_net64.py): stored weights or formula weights, as there"""
+    if tag == "b10f16":
+        return load_net(np.load(os.path.join(golden_dir, "net.npz")), "b10f16", 10, 16, device=device), False
+    if tag == "b2f32":
+        return load_net(np.load(os.path.join(golden_dir, "net_wide.npz")), "b2f32", 2, 32, device=device), False
+    blocks, filters, salt, use_tanh = DEEP[tag]
+    return load_formula_net(blocks, filters, salt, use_tanh, device=device), use_tanh
+
+
+def check_net64(golden_dir, tag, net, use_tanh, device="cpu", tol=TOL):
+    """value, 768 sampled logits, and the sum / L2 norm of all 11 583 logits of the 64 fixture positions (tall stacks,
+    garbage-heavy and nearly empty boards: what the activations' magnitude depends on) against the reference's"""
+    d = np.load(os.path.join(golden_dir, "net64.npz"))
+    grids, vec = packed_features(d["states"])
+    v, logits = net.heads(torch.from_numpy(grids).to(device), torch.from_numpy(vec).to(device))
+    v = (torch.tanh(v) if use_tanh else torch.sigmoid(v)).cpu().numpy()
+    lg = logits.cpu().numpy()
+    err = np.abs(lg[:, d["sampled"]] - d["%s/sampled_logits" % tag]).max()
+    assert np.abs(v - d["%s/values" % tag]).max() < tol
+    assert err < tol, err
+    # sums over 11 583 logits of magnitude ~1: per-logit errors of 1e-5 could add up to 0.1; they do not get near it
+    assert np.abs(lg.astype(np.float64).sum(axis=1) - d["%s/logit_sum" % tag]).max() < 5e-3
+    assert np.abs(np.sqrt((lg.astype(np.float64) ** 2).sum(axis=1)) - d["%s/logit_l2" % tag]).max() < 1e-4
+    return err
+
+
+@pytest.mark.parametrize("tag", NET64)
+def test_64_positions_match_reference(golden_dir, tag):
+    net, use_tanh = load_net64(golden_dir, tag)
+    check_net64(golden_dir, tag, net, use_tanh)
+
+
+def scaled_copy(net, what):
+    """b10f16 with one block rescaled by a power of two -- the same function (and, powers of two being exact, the same
+    fp32 results in the reference's own forward), but a different operand range for the split tower kernels:
+      'weight': block 3's second batch norm x 1024, its second conv / 1024 -> folded first-conv weights up to ~85 (>= 31:
+                the packer refuses the split layout, the fp32 kernels run);
+      'activation': block 3's first batch norm x 2^17, its first conv / 2^17 -> relu(bn1(x)) reaches ~1e6 (>= 65 504: no
+                f16 hi half), every folded weight stays small."""
+    import copy
+    m = copy.deepcopy(net)
+    blk = m.res_blocks[3]
+    with torch.no_grad():
+        if what == "weight":
+            blk.conv_block2["0"].weight.mul_(1024.0); blk.conv_block2["0"].bias.mul_(1024.0)
+            blk.conv_block2["3"].weight.div_(1024.0)
+        else:
+            blk.conv_block1["0"].weight.mul_(131072.0); blk.conv_block1["0"].bias.mul_(131072.0)
+            blk.conv_block1["2"].weight.div_(131072.0)
+    m._folded = None
+    return m
+
+
 def test_reference_checkpoint_roundtrip(tmp_path, golden_dir):
     d = np.load(os.path.join(golden_dir, "net.npz"))
     net = load_net(d, "b2f8", 2, 8)

@@ -31,6 +31,15 @@ def _worker(rank, world, port, q):
     parallel.broadcast_state_dict(net, dist)
     digest = [float(v.double().sum()) for v in net.state_dict().values()]
     ints = parallel.all_gather_ints([rank, 10 * rank + 1], dist).tolist()
+    # host-side rendezvous in front of a collective (self_play_loop: rank 0 trains while the others wait): rank 1 returns
+    # from the wait only after rank 0 has arrived
+    import time
+    if rank == 0:
+        time.sleep(1.0)
+    t0 = time.perf_counter()
+    parallel.wait_for_rank0(dist)
+    waited = time.perf_counter() - t0
+    assert rank == 0 or waited > 0.5, waited
     q.put((rank, streams.tolist(), elapsed, units, None if got is None else [g.tolist() for g in got], digest, ints))
     dist.barrier()
     dist.destroy_process_group()

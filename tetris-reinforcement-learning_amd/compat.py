@@ -227,7 +227,7 @@ def MCTS(config, game, interference_network, policy_head="full"):
     e = _eng.Engine(1, ruleset=game.ruleset, seed=game.seed, device=dev.index or 0,
                     stream=torch.cuda.current_stream(dev).cuda_stream)
     e.set_state(game._pack()[None])
-    e.mcts_create(selfplay.search_options(config, auto_reset=0))
+    e.mcts_create(selfplay.search_options(config, auto_reset=0, random_start=0))    # random openings are play_game's (ai.py:1588-1608)
     grids = torch.zeros((2, 1, _eng.GRID_FLOATS), dtype=torch.float32, device=dev)
     vec = torch.zeros((1, _eng.VEC_FLOATS), dtype=torch.float32, device=dev)
     rec, sims = None, 0

@@ -173,6 +173,9 @@ __global__ __launch_bounds__(BLOCK, 8) void k_rollout(trl_game_state *states, ui
             if (tid == 0 && (total == 0 || is_terminal(g) || (int)g.ply >= max_plies)) {
                 uint32_t stream = g.stream + 0x01000000u, episode = g.episode + 1;
                 int ruleset = g.ruleset; uint8_t flags = g.flags;
+                // episode e runs on stream + e * 2^24 in uint32: the 256th re-setup lands on the slot's first stream again and
+                // the slot replays its games from there -- said in the state (the search refuses this up front, trl_mcts_create)
+                if (episode >= 256u) flags |= TRL_FLAG_STREAM_WRAP;
                 game_setup(g, ruleset, seed, stream);
                 g.episode = episode; g.flags = flags;
             }

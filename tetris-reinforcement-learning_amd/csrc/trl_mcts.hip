@@ -791,11 +791,12 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
             __syncthreads();
             if (tid == 0) {
                 const int quota = cfg.episodes_base + (slot < cfg.episodes_extra ? 1 : 0);      // 0: no limit
-                if (cfg.auto_reset && sh.g.episode + 1 >= 256u) {
+                const bool quota_met = quota > 0 && (int)sh.g.episode + 1 >= quota;     // first: a quota of exactly 256 ends cleanly
+                if (cfg.auto_reset && !quota_met && sh.g.episode + 1 >= 256u) {
                     // the next episode's stream (+ 2^24 per episode) would wrap onto this slot's first one and replay its games
                     sh.ctl.overflow = 1; atomicAdd(&M.counters[5], 1ull);
                     sh.ctl.phase = 2;
-                } else if (cfg.auto_reset && !(quota > 0 && (int)sh.g.episode + 1 >= quota)) {
+                } else if (cfg.auto_reset && !quota_met) {
                     trl_game_state &g = sh.g;
                     uint32_t stream = g.stream + 0x01000000u, episode = g.episode + 1;
                     int ruleset = g.ruleset; uint8_t flags = g.flags;

@@ -288,6 +288,13 @@ constexpr float SPLIT = 2048.f, INV_SPLIT = 1.f / 2048.f;
 
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
+// workgroups (boards) of the split towers whose activations left the f16 range since the counter was last reset
+__device__ unsigned int g_split_overflow;
+constexpr float SPLIT_ACT_MAX = 65504.f;         // largest finite f16
+__device__ __forceinline__ void report_split_range(float mx) {      // all threads of the workgroup, once, after the last conv
+    if (__syncthreads_or(mx >= SPLIT_ACT_MAX) && threadIdx.x == 0) atomicAdd(&g_split_overflow, 1u);
+}
+
 // four values (the lane's four channels of one position) -> hi and lo halves, one 8-byte store each.
 // lo = f16((v - hi) * 2^11) as ONE v_fma_mix per value: fma(hi, -2^11, 2^11 v) -- the f16 source is widened inside the
 // instruction, the sum is exact (|v - hi| <= 2^-11 |v|, so 2^11 (v - hi) has at most 13 significant bits) and the result is
@@ -300,7 +307,12 @@ __device__ __forceinline__ unsigned lo_pair(unsigned hpair, float a2, float b2) 
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(d) : "v"(hpair), "v"(negs), "v"(b2));
     return d;
 }
-__device__ __forceinline__ void store_split4(_Float16 *hi, _Float16 *lo, int idx, f32x4 v) {
+// `mx`: running maximum of everything this lane has split (the values are ReLU outputs, >= 0): two v_max3_f32 per call.  A
+// value of 65 520 or more has no f16 hi half (it rounds to infinity and the convolution that reads it returns inf / NaN,
+// which the next ReLU may even turn into a plausible 0): the kernels report it through g_split_overflow instead of
+// returning such numbers silently (trl_tower_overflow; nets.py re-runs the board on the fp32 kernels).
+__device__ __forceinline__ void store_split4(_Float16 *hi, _Float16 *lo, int idx, f32x4 v, float &mx) {
+    mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
     const f16x4 h = __builtin_convertvector(v, f16x4);                  // 2 x v_cvt_pk_f16_f32 (round to nearest even)
     const f32x4 v2 = v * SPLIT;
     const uint2 hp = __builtin_bit_cast(uint2, h);
@@ -462,6 +474,7 @@ __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *_
     const float *wb = wts + 400;
     f32x4 am[7];
     SW w;
+    float act_max = 0.f;            // largest activation this lane has split (store_split4)
 #ifdef TRL_PROFILE
     unsigned long long tprof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -477,7 +490,7 @@ __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *_
             if ((s < 6 || wave == 0) && (TRL_EXP != 7 || s == 0)) {
                 f32x4 v = __builtin_elementwise_fma(x[s], s1, t1);
                 v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                store_split4(const_cast<_Float16 *>(sb[s].p0), const_cast<_Float16 *>(sb[s].p0) + LO_OFS, WOFS, v);
+                store_split4(const_cast<_Float16 *>(sb[s].p0), const_cast<_Float16 *>(sb[s].p0) + LO_OFS, WOFS, v, act_max);
             }
         }
         TPROF_T(tp1);
@@ -503,7 +516,7 @@ __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *_
             if ((s < 6 || wave == 0) && (TRL_EXP != 7 || s == 0)) {
                 f32x4 v = am[s];
                 v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                store_split4(const_cast<_Float16 *>(sb[s].p0), const_cast<_Float16 *>(sb[s].p0) + LO_OFS, WOFS, v);
+                store_split4(const_cast<_Float16 *>(sb[s].p0), const_cast<_Float16 *>(sb[s].p0) + LO_OFS, WOFS, v, act_max);
             }
         }
         TPROF_T(tp5);
@@ -536,6 +549,7 @@ __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *_
             for (int i = 0; i < 10; i++) g_tprof[((blockIdx.x ? 1 : 0) * 8 + wave) * 10 + i] = tprof[i];
     }
 #endif
+    report_split_range(act_max);
     // tail: relu(bn(x)) -> 1x1 conv over the 16 channels (4 in the lane, 4 lane groups) -> folded bn -> relu   (fp32)
     const f32x4 s = *reinterpret_cast<const f32x4 *>(wb + 4 * g), t = *reinterpret_cast<const f32x4 *>(wb + 16 + 4 * g);
     const f32x4 wk = *reinterpret_cast<const f32x4 *>(wb + 32 + 4 * g);
@@ -1004,6 +1018,7 @@ __global__ __launch_bounds__((WideS<FF>::THREADS), 2) void k_trunk_wide_s(const 
     const _Float16 *hiL = hiP + g * W::PLANEH, *loL = loP + g * W::PLANEH;
     const float *wb = wts + FF * STEM + (POST ? FF : 0);
     f32x4 am[TS];
+    float act_max = 0.f;            // largest activation this lane has split (store_split4)
 #ifdef TRL_PROFILE
     unsigned long long tprof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -1035,7 +1050,7 @@ __global__ __launch_bounds__((WideS<FF>::THREADS), 2) void k_trunk_wide_s(const 
         for (int s = 0; s < (TRL_EXP == 3 ? 1 : TS); s++) {
             if (s < 12 || mq == 0) {                   // (tile 25 does not exist)
                 const f32x4 v = relu4(first ? (POST ? x[s] : __builtin_elementwise_fma(x[s], sc, sh)) : am[s]);
-                store_split4(ownh, ownl, base[s], v);
+                store_split4(ownh, ownl, base[s], v, act_max);
             }
         }
         TPROF_T(tp1);
@@ -1070,6 +1085,7 @@ __global__ __launch_bounds__((WideS<FF>::THREADS), 2) void k_trunk_wide_s(const 
     }
 #endif
 
+    report_split_range(act_max);
     float *part = lds;                                 // [kout][NN][400] partial sums (the planes are dead now)
     if (POST) {
         for (int k = 0; k < kout; k++) {               // tail: kout 1x1 projections of the feature map, raw
@@ -1212,6 +1228,20 @@ int trl_resnet_trunk(const float *dev_boards, int n_boards, const float *dev_pac
     else
         return fail(TRL_E_INVALID, "trl_resnet_trunk: %s", "the fused tower exists for 32 and 64 filters");
     HIPCHK(hipGetLastError());
+    return TRL_OK;
+}
+
+// Range guard of the split towers (k_trunk16s / k_trunk_wide_s): the number of boards, since the last reset, in which an
+// activation reached the largest finite f16 (65 504) when it was split into halves -- their outputs are not to be trusted
+// (inf / NaN inside the tower); the fp32 towers (trl_alphasame_trunk / trl_resnet_trunk) have no such limit.  The caller
+// synchronises the stream(s) its towers ran on first; `device` = HIP device ordinal.
+int trl_tower_overflow(int device, int reset, uint32_t *count_out) {
+    if (!count_out) return fail(TRL_E_INVALID, "trl_tower_overflow: %s", "null argument");
+    HIPCHK(hipSetDevice(device));
+    unsigned int c = 0;
+    HIPCHK(hipMemcpyFromSymbol(&c, HIP_SYMBOL(g_split_overflow), sizeof c));
+    if (reset && c) { const unsigned int z = 0; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_split_overflow), &z, sizeof z)); }
+    *count_out = c;
     return TRL_OK;
 }
 

@@ -24,6 +24,7 @@ ABI_SYMBOLS = [
     "trl_env_rollout_random", "trl_last_kernel_ms",
     "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_expand_head", "trl_mcts_drain_records", "trl_mcts_drain_records_dev", "trl_mcts_get_stats",
     "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16", "trl_alphasame_trunk16_need", "trl_alphasame_trunk16_split", "trl_trunk_wide_split", "trl_alphasame_trunk", "trl_resnet_trunk", "trl_graph_begin", "trl_graph_end", "trl_graph_end_many", "trl_graph_launch",
+    "trl_tower_overflow",
     "trl_mcts_select_need", "trl_mcts_fork_legal", "trl_mcts_expand_alphasame_masked", "trl_mcts_zcache", "trl_mcts_zcache_dim", "trl_mcts_expand_alphasame", "trl_mcts_expand_alphasame_select", "trl_mcts_restart",
 ]
 
@@ -151,8 +152,18 @@ def load_library(path=None):
     L.trl_alphasame_trunk16.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.trl_alphasame_trunk.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.trl_resnet_trunk.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.trl_tower_overflow.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint32)]
     _lib = L
     return L
+
+
+def tower_overflow(device=0, reset=True):
+    """boards whose activations left the f16 range inside a split tower since the last reset (trl_tower_overflow); the
+    caller has synchronised the streams its towers ran on"""
+    L = load_library()
+    n = C.c_uint32(0)
+    _check(L, L.trl_tower_overflow(int(device), int(bool(reset)), C.byref(n)), "trl_tower_overflow")
+    return int(n.value)
 
 
 def _check(L, rc, what):

@@ -61,7 +61,8 @@ class Battle:
         if streams is None and index_base:
             streams = np.arange(index_base, index_base + self.n, dtype=np.uint32)
         self.engine.reset(streams)
-        self.engine.mcts_create(selfplay.search_options(config, auto_reset=0))
+        # only play_game opens with random moves (ai.py:1588-1608): a gating match searches from ply 0
+        self.engine.mcts_create(selfplay.search_options(config, auto_reset=0, random_start=0))
         self.evals = (eval_1, eval_2)
         for ev in self.evals:
             if hasattr(ev, "bind"):
@@ -129,8 +130,11 @@ class Battle:
                     ended += 1
                     self.winners[int(r["slot"])] = int(r["winner"])
         st = self.engine.mcts_stats()
-        if st["records_dropped"] or st["overflow"]:
-            raise _eng.EngineError("device record buffer or tree capacity overflowed: %r" % (st,))
+        if self.nets is not None and any(getattr(m, "tower_mode", "") == "split" for m in self.nets):
+            st["tower_overflow"] = _eng.tower_overflow(self.device.index or 0, reset=True)     # the stream is synchronised
+        if st["records_dropped"] or st["overflow"] or st.get("tower_overflow"):
+            raise _eng.EngineError("device record buffer or tree capacity overflowed, or (tower_overflow) an activation left "
+                                   "the f16 range of the split tower kernels -- set tower_mode = 'fp32' on the networks: %r" % (st,))
         return tally_concurrent([self.winners[k] for k in range(self.n)], self.index_base) if ended == self.n else wins
 
 
@@ -150,11 +154,14 @@ def tally_concurrent(winners, first=0):
 
 def scan_sequential(wins, winners, first, games, threshold, threshold_type):
     """The sequential loop's bookkeeping (ai.py:2019-2046) over games first, first + 1, ... whose winners are known:
-    updates the integer `wins` in place and returns (games consumed, True / False when a threshold was met, else None)."""
+    updates the float `wins` in place and returns (games consumed, True / False when a threshold was met, else None).
+    A drawn game (MAX_MOVES reached) counts half a point for each network; the reference's own `wins += 0.5` on its
+    integer array raises numpy's UFuncTypeError there (ai.py:2021), which would abort self_play_loop after the set was
+    generated and the challenger trained -- not reproduced."""
     for k, winner in enumerate(winners):
         flip_color = (first + k) % 2 == 1
         if winner == -1:
-            wins += 0.5                                   # as the reference: numpy refuses this on an integer array
+            wins += 0.5
         elif not flip_color:
             wins[winner] += 1
         else:
@@ -163,6 +170,11 @@ def scan_sequential(wins, winners, first, games, threshold, threshold_type):
         if accepted is not None:
             return k + 1, accepted
     return len(winners), None
+
+
+def _as_reference_wins(wins):
+    """the sequential form's result array: int64 like the reference's when every game had a winner"""
+    return wins.astype(int) if np.all(wins == np.floor(wins)) else wins
 
 
 def _fresh_seed():
@@ -177,8 +189,9 @@ def battle_networks(NN_1, config_1, NN_2, config_2, threshold, threshold_type, g
     Which form runs follows the reference: both configs model == 'pytorch' with batched_inference -> the concurrent form
     (_battle_networks_async + _check_threshold, float wins); otherwise the sequential form: integer wins, games in index
     order, return at the first game after which either network meets the threshold (ai.py:2031-2046) -- played in waves of
-    `wave` concurrent games, later waves are not started once the scan has stopped.  (A drawn game in the sequential form
-    does `wins += 0.5` on an integer array, which numpy refuses as in the reference.)
+    `wave` concurrent games, later waves are not started once the scan has stopped.  (A drawn game counts half a point
+    each: the wins come back as integers when no game was drawn -- the reference's array -- and as floats otherwise,
+    where the reference's `wins += 0.5` on its integer array raises.)
     seed=None: fresh randomness per match, as the reference's; an int makes the match reproducible (game i = stream i).
     dist: an initialised torch.distributed module -> rank r plays games [r * G / W, (r + 1) * G / W), the winners are
     all-gathered and every rank returns the same result (either form; no wave savings when sharded).
@@ -222,19 +235,19 @@ def battle_networks(NN_1, config_1, NN_2, config_2, threshold, threshold_type, g
         if use_async:
             wins = tally_concurrent(winners)
             return wins, _check_threshold(wins, games, threshold, threshold_type)
-        wins = np.zeros(2, dtype=int)
+        wins = np.zeros(2, dtype=float)
         _, accepted = scan_sequential(wins, winners, 0, games, threshold, threshold_type)
-        return wins, accepted
+        return _as_reference_wins(wins), accepted
     if use_async:
         wins = tally_concurrent(play(0, games))
         return wins, _check_threshold(wins, games, threshold, threshold_type)
 
-    wins = np.zeros(2, dtype=int)                         # ai.py:1991
+    wins = np.zeros(2, dtype=float)                       # ai.py:1991 (integers there)
     i = 0
     while i < games:
         count = min(int(wave), games - i)
         _, accepted = scan_sequential(wins, play(i, count), i, games, threshold, threshold_type)
         if accepted is not None:
-            return wins, accepted
+            return _as_reference_wins(wins), accepted
         i += count
-    return wins, None
+    return _as_reference_wins(wins), None

@@ -135,6 +135,26 @@ def _split_or_none(pack):
         return None
 
 
+class SplitActivationRange(RuntimeWarning):
+    """an activation of a split tower reached the f16 range (|a| >= 65 504): the result was recomputed on the fp32 kernels"""
+
+
+def _split_overflowed(device):
+    """eager callers of a split tower: wait for it and ask the library whether an activation left the f16 range
+    (trl_tower_overflow); never inside a stream capture (SelfPlay / Battle ask at their own synchronisation points)"""
+    if torch.cuda.is_current_stream_capturing():
+        return False
+    from . import engine as _eng
+    torch.cuda.current_stream(device).synchronize()
+    return _eng.tower_overflow(device.index or 0, reset=True) > 0
+
+
+def _warn_split_range(what):
+    import warnings
+    warnings.warn("%s: an activation reached the f16 range of the split tower kernels (|a| >= 65504); this network runs on "
+                  "the fp32 tower kernels from here on (tower_mode = 'fp32')" % what, SplitActivationRange, stacklevel=3)
+
+
 class AlphaSame(nn.Module):
     def __init__(self, model_config=None, use_tanh=False):
         super().__init__()
@@ -239,7 +259,12 @@ class AlphaSame(nn.Module):
         """boards float[m, 1, 40, 10] -> float[m, 400] (process_grid of the reference, architectures.py:121-127)"""
         fd = self._folded or self.prepare()._folded
         if fd["packed_tower"] is not None and self.use_hip_trunk:
-            return self._trunk_hip(boards, fd["packed_tower"])
+            out = self._trunk_hip(boards, fd["packed_tower"])
+            if self.tower_mode == "split" and fd.get("packed_split") is not None and _split_overflowed(boards.device):
+                _warn_split_range("AlphaSame.trunk")
+                self.tower_mode = "fp32"
+                out = self._trunk_hip(boards, fd["packed_tower"])
+            return out
         x = F.conv2d(boards, self.conv1.weight, padding=2)
         for s1, t1, wa, ba, wb in fd["blocks"]:
             h = torch.relu(x * s1 + t1)
@@ -530,6 +555,10 @@ class BaseResNet(nn.Module):
         if hip:
             if z is None:
                 z = self._tower_hip(grids.reshape(2 * n, ROWS * COLS), fd["packed_tower"])
+                if self.tower_mode == "split" and fd.get("packed_split") is not None and _split_overflowed(grids.device):
+                    _warn_split_range(type(self).__name__)
+                    self.tower_mode = "fp32"
+                    z = self._tower_hip(grids.reshape(2 * n, ROWS * COLS), fd["packed_tower"])
             z = z.reshape(2 * n, self.model_config.own_kernels + 1, ROWS * COLS)
             k = self.model_config.own_kernels
             o_col = torch.relu(z[n:, k] + fd["opp"][1])

@@ -88,6 +88,31 @@ def gather_bytes(payload, dist=None, device=None, dst=0):
     return [p.cpu().numpy() for p in parts]
 
 
+_wait_seq = 0
+
+
+def wait_for_rank0(dist, hours=48.0):
+    """Host-side rendezvous in front of a collective that the other ranks would otherwise sit in while rank 0 works
+    alone (training the challenger): a rank parked INSIDE an RCCL / gloo collective is subject to the process group's
+    timeout (10 minutes by default) and takes the job down when rank 0 needs longer.  Rank 0 sets a key in the group's
+    store when it arrives, the others wait for it there -- the store's wait takes its own, long timeout.  Every rank
+    calls this the same number of times; no-op without a group."""
+    global _wait_seq
+    if not active(dist):
+        return
+    from datetime import timedelta
+    _wait_seq += 1
+    key = "trl_rank0_ready_%d" % _wait_seq
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:
+        return                                    # no store to wait on: the collective itself is the rendezvous
+    if dist.get_rank() == 0:
+        store.set(key, "1")
+    else:
+        store.wait([key], timedelta(hours=hours))
+
+
 def broadcast_state_dict(module, dist, src=0):
     """rank `src`'s parameters and buffers to every rank, in place (the refreshed weights of the outer loop,
     SURVEY.md section 8e: one flat bucket, one broadcast -- 24 MB for AlphaSame(10, 16))"""

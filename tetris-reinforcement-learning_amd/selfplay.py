@@ -286,11 +286,19 @@ class SelfPlay:
             if self._rec_dev is None:
                 self._rec_dev = torch.empty(cap * _eng.RECORD_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
             n = self.engine.mcts_drain_records_dev(self._rec_dev.data_ptr(), cap)
-            return self._rec_dev[:n * _eng.RECORD_DTYPE.itemsize].clone()
+            out = self._rec_dev[:n * _eng.RECORD_DTYPE.itemsize].clone()
+        # the clone was enqueued on this object's stream; its readers (torch.cat, the RCCL gather) run on theirs
+        self.stream.synchronize()
+        return out
 
     def stats(self):
+        """trl_mcts_stats + "tower_overflow": boards (since the last call, on this device) whose activations left the f16
+        range of the split tower kernels -- the searches that evaluated them ran on wrong priors; callers treat it like a
+        tree overflow (the remedy: network.tower_mode = 'fp32')"""
         self.stream.synchronize()
-        return self.engine.mcts_stats()
+        st = self.engine.mcts_stats()
+        st["tower_overflow"] = _eng.tower_overflow(self.device.index or 0, reset=True) if getattr(self.net, "tower_mode", "") == "split" else 0
+        return st
 
 
 class SelfPlayGroups:
@@ -500,7 +508,7 @@ def _play_collect(config, network, num_games, seed, device=0, max_slots=1024, st
         else:
             r = sp.drain()
         st = sp.stats()
-        bad = int(bool(st["records_dropped"] or st["overflow"]))
+        bad = int(bool(st["records_dropped"] or st["overflow"] or st["tower_overflow"]))
         local_done = st["games"] >= num_games
         if multi:
             if not nccl:
@@ -510,7 +518,8 @@ def _play_collect(config, network, num_games, seed, device=0, max_slots=1024, st
         else:
             all_done = local_done
         if bad:                                                # every rank leaves the loop together
-            raise _eng.EngineError("device record buffer or tree capacity overflowed: %r" % (st,))
+            raise _eng.EngineError("device record buffer or tree capacity overflowed, or (tower_overflow) an activation left "
+                                   "the f16 range of the split tower kernels -- set network.tower_mode = 'fp32': %r" % (st,))
         if not local_done:
             sp.tick(chunk)                                     # the device goes on while the records travel / are converted
         if multi:
@@ -714,6 +723,7 @@ def self_play_loop(config, skip_first_set=False, max_sets=None, train_fn=None, g
         if rank == 0:
             (train_fn or learner.load_data_and_train_model)(config, challenger)
             next_ver = highest_model_number(config) + 1
+        parallel.wait_for_rank0(dist)                      # training may outlast the backend's collective timeout: wait on the host
         parallel.broadcast_state_dict(challenger, dist)    # the trained challenger to every rank for the sharded match
         if hasattr(challenger, "_folded"):
             challenger._folded = None
@@ -722,6 +732,8 @@ def self_play_loop(config, skip_first_set=False, max_sets=None, train_fn=None, g
         params = inspect.signature(gate).parameters
         if "seed" in params:
             tagm = (highest_data_number(config), highest_model_number(config))
+            if multi:                                      # Storage/ may be rank 0's only: every rank derives the gate seed
+                tagm = parallel.all_gather_ints(tagm, dist, dev if dist.get_backend() == "nccl" else None)[0]   # from rank 0's numbers
             kw["seed"] = None if seed is None else derive_seed(seed, "gate", int(tagm[0]), int(tagm[1]), it)
         if "dist" in params and multi:
             kw["dist"] = dist
