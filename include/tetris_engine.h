@@ -233,6 +233,8 @@ typedef struct trl_mcts_config {      /* Config fields the search reads (ai.py:6
     int32_t random_start;             /* Config.use_random_starting_moves: see below */
     int32_t episodes_base;            /* with auto_reset: slot s plays episodes_base + (s < episodes_extra) games, then idles */
     int32_t episodes_extra;           /* (0, 0 = no limit).  Episode e of a slot runs on RNG stream + e * 2^24: at most 256 */
+    int32_t move_algorithm;           /* Config.move_algorithm (ai.py:84, 414): TRL_ALGO_CONVOLUTIONAL (default) / TRL_ALGO_BRUTE_FORCE */
+    int32_t reserved0;
     double  cpuct, dpuct;             /* CPUCT, DPUCT */
     double  fpu_value;                /* FpuValue */
     double  root_softmax_temp;        /* RootSoftmaxTemp */

@@ -168,7 +168,7 @@ class MctsConfig(C.Structure):
                 ("playout_cap_chance", C.c_double), ("playout_cap_mult", C.c_double),
                 ("use_dirichlet", C.c_int), ("dir_alpha", C.c_double), ("dir_s", C.c_double), ("dir_expl", C.c_double),
                 ("use_dir_s", C.c_int), ("use_forced", C.c_int), ("c_forced", C.c_double), ("use_tanh", C.c_int),
-                ("random_start", C.c_int)]
+                ("random_start", C.c_int), ("move_algorithm", C.c_int)]
 
 
 class MctsResult(C.Structure):
@@ -183,7 +183,7 @@ def default_mcts_config(**kw):
     c = MctsConfig(max_iter=160, cpuct=0.75, dpuct=1.0, fpu_reduction=1, fpu_value=0.1, use_root_softmax=1,
                    root_softmax_temp=1.1, temperature=0.1, training=0, use_playout_cap=1, playout_cap_chance=0.25,
                    playout_cap_mult=5.0, use_dirichlet=1, dir_alpha=0.1, dir_s=25.0, dir_expl=0.25, use_dir_s=1,
-                   use_forced=0, c_forced=1.0, use_tanh=0, random_start=0)
+                   use_forced=0, c_forced=1.0, use_tanh=0, random_start=0, move_algorithm=0)
     for k, v in kw.items():
         setattr(c, k, v)
     return c

@@ -671,10 +671,13 @@ int to_move_matrix(const to_player *pl, int ruleset, int algo, uint8_t *mask) {
     return n;
 }
 
-int to_legal_moves(const to_game *g, uint16_t *out) {
+int to_legal_moves(const to_game *g, uint16_t *out) { return to_legal_moves_algo(g, 0, out); }
+
+/* get_move_matrix(player, algo=config.move_algorithm) + get_move_list (ai.py:414-417): algo 0 'convolutional', 1 'brute-force' */
+int to_legal_moves_algo(const to_game *g, int algo, uint16_t *out) {
     if (to_is_terminal(g) || to_no_move(g)) return 0;
     uint8_t mask[TRL_POLICY_SIZE];
-    to_move_matrix(&g->p[g->turn], g->ruleset, 0, mask);
+    to_move_matrix(&g->p[g->turn], g->ruleset, algo, mask);
     int n = 0;
     for (int pi = 0; pi < TRL_PLANES; pi++)                 /* np.argwhere order, ai.py:1019 */
         for (int r = 0; r < TRL_POLICY_ROWS; r++)

@@ -187,7 +187,7 @@ int to_mcts(to_game *game, const to_mcts_config *cfg, to_eval_fn eval, void *ctx
             eval(lg, &v32, policy, ctx);
             value = (double)v32;
             if (!to_no_move(lg)) {
-                int n = to_legal_moves(lg, moves);
+                int n = to_legal_moves_algo(lg, cfg->move_algorithm, moves);
                 int is_root = (node == root);
                 int first = T.n_nodes;
                 if (is_root && cfg->use_root_softmax) {

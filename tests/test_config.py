@@ -36,8 +36,10 @@ def test_copy_and_dirs(monkeypatch, tmp_path):
 
 
 def test_search_options_reject_what_the_device_lacks():
-    with pytest.raises(ValueError):
-        trl.search_options(trl.Config(move_algorithm="brute-force"))
+    with pytest.raises(ValueError, match="Unknown algorithm"):        # the reference's two lossy generators are not built
+        trl.search_options(trl.Config(move_algorithm="harddrop"))
+    assert trl.search_options(trl.Config(move_algorithm="brute-force")).move_algorithm == 1      # ai.py:84, 414
+    assert trl.search_options(trl.Config()).move_algorithm == 0
     with pytest.raises(ValueError):
         trl.search_options(trl.Config(FpuStrategy="nope"))
     o = trl.search_options(trl.Config(MAX_ITER=160, training=True))

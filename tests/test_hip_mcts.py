@@ -432,3 +432,40 @@ def test_a_quota_of_exactly_256_games_ends_cleanly():
         assert sorted(ends) == [254, 254, 255, 255], ends
         assert stats["games"] == 4 and bool(stats["overflow"]) == bool(want_overflow), (quota, stats)
         eng.close()
+
+
+def test_search_with_the_brute_force_generator_matches_reference(golden_dir):
+    """Config.move_algorithm = 'brute-force' inside the search (ai.py:84, 414; k_select_bf): root children, visits and
+    chosen moves of the reference's searches on T-piece positions where its two generators disagree -- and the same
+    positions with 'convolutional'; also through the package's Config / SelfPlay path (three-kernel tick)"""
+    d = np.load(os.path.join(golden_dir, "mcts_bf.npz"))
+    off = np.concatenate([[0], np.cumsum(d["child_counts"])])
+    for algo in (1, 0):
+        idx = np.nonzero(d["algo"] == algo)[0]
+        eng = trl.Engine(len(idx), seed=int(d["seed"]))
+        eng.set_state(d["states"][idx])
+        s = StubSearch(eng, trl.mcts_config(max_iter=int(d["max_iter"]), training=0, auto_reset=0, move_algorithm=algo))
+        for t in range(int(d["max_iter"])):
+            s.tick()
+        recs = eng.mcts_drain_records()
+        recs = recs[recs["kind"] == trl.REC_MOVE]
+        recs = recs[np.argsort(recs["slot"], kind="stable")]
+        assert len(recs) == len(idx) and eng.mcts_stats()["overflow"] == 0
+        for j, ci in enumerate(idx):
+            sl = slice(off[ci], off[ci + 1])
+            n = int(recs["n_children"][j])
+            assert n == d["child_counts"][ci] and np.array_equal(recs["moves"][j][:n], d["child_moves"][sl]), (algo, ci)
+            assert np.array_equal(recs["visits"][j][:n].astype(np.int32), d["child_visits"][sl]), (algo, ci)
+            assert int(recs["chosen"][j]) == d["move"][ci], (algo, ci)
+    with pytest.raises(trl.EngineError):
+        trl.Engine(1, seed=1).mcts_create(trl.mcts_config(move_algorithm=2))
+    # Config(move_algorithm='brute-force') -> SelfPlay: plays, on the three-kernel tick
+    import torch
+    torch.manual_seed(0)
+    mc = trl.AlphaSameConfig(blocks=2, filters=16)
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=8, training=True, move_algorithm="brute-force")
+    sp = trl.SelfPlay(cfg, trl.AlphaSame(mc), 16, seed=3)
+    assert not sp.fused_select and sp.native_graph
+    sp.tick(64)
+    st = sp.stats()
+    assert st["simulations"] == 64 * 16 and st["overflow"] == 0 and st["moves"] > 16

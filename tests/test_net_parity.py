@@ -252,3 +252,62 @@ def test_split_pack_refuses_weights_out_of_range():
         warnings.simplefilter("always")
         assert nets._split_or_none(lambda: nets._pack_conv3x3_split(w)) is None
     assert got and "fp32 tower" in str(got[0].message)
+
+
+def test_keras_weight_port_layout():
+    """nets.port_keras_weights (util.py:2369-2464) -- PARITY UNPINNED: Keras is not importable here, so
+    nothing Keras computed can be compared.  What can be checked is the layout algebra, on synthetic weights: a
+    channels-last ("Keras-side") evaluation of every layer kind with the Keras-layout arrays must equal the PyTorch
+    module's evaluation with the ported parameters -- conv kernels (HWIO), dense kernels (in, out), batch-norm statistics,
+    and the three heads that read the own-side map flattened in [r, c, k] order instead of PyTorch's [k, r, c]."""
+    rng = np.random.default_rng(5)
+    mc = nets.AuxBaseResNetConfig(blocks=2, filters=8, opp_hidden=16, own_kernels=3, value_hidden=8, aux_hidden=8)
+    f, k = mc.filters, mc.own_kernels
+    head_in = k * 400 + 49 + 3 + 1
+    r = lambda *s: rng.standard_normal(s).astype(np.float32)
+    bn = lambda c: [1 + 0.1 * r(c), 0.1 * r(c), 0.1 * r(c), (0.5 + rng.random(c)).astype(np.float32)]
+    kw = {"stem_conv": [r(3, 3, 1, f)], "stem_bn": bn(f)}
+    for i in range(mc.blocks):
+        kw.update({"block%d_conv1" % i: [r(3, 3, f, f)], "block%d_bn1" % i: bn(f), "block%d_conv2" % i: [r(3, 3, f, f)], "block%d_bn2" % i: bn(f)})
+    kw.update({"opp_collapse_conv": [r(1, 1, f, 1)], "opp_collapse_bn": bn(1), "opp_encode_dense": [r(400 + 52, mc.opp_hidden), r(mc.opp_hidden)],
+               "opp_encode_bn": bn(mc.opp_hidden), "bias_project": [r(mc.opp_hidden + 53, f), r(f)],
+               "own_collapse_conv": [r(1, 1, f, k)], "own_collapse_bn": bn(k), "policy": [0.01 * r(head_in, 11583), r(11583)],
+               "value_hidden": [r(head_in, mc.value_hidden), r(mc.value_hidden)], "value_hidden_bn": bn(mc.value_hidden),
+               "value": [r(mc.value_hidden, 1), r(1)], "aux_hidden": [r(head_in, mc.aux_hidden), r(mc.aux_hidden)],
+               "aux_hidden_bn": bn(mc.aux_hidden), "aux": [r(mc.aux_hidden, 2), r(2)]})
+    net = nets.port_keras_weights(kw, mc)
+    sd = net.state_dict()
+    # conv: channels-last correlation with the HWIO kernel == F.conv2d with the ported OIHW weight
+    x = r(2, 40, 10, f)                                                     # (B, H, W, C)
+    kern = kw["block1_conv2"][0]
+    xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))
+    want = sum(np.einsum("bhwc,co->bhwo", xp[:, dy:dy + 40, dx:dx + 10, :], kern[dy, dx]) for dy in range(3) for dx in range(3))
+    got = torch.nn.functional.conv2d(torch.from_numpy(x.transpose(0, 3, 1, 2).copy()), sd["trunk.1.conv2.weight"], padding=1)
+    assert np.abs(got.numpy().transpose(0, 2, 3, 1) - want).max() < 1e-4
+    # batch norm: [gamma, beta, mean, var] -> weight, bias, running_mean, running_var
+    for name, a in zip(("weight", "bias", "running_mean", "running_var"), kw["block0_bn1"]):
+        assert np.array_equal(sd["trunk.0.bn1." + name].numpy(), a)
+    # dense: x @ K + b == F.linear(x, W, b)
+    v = r(3, mc.opp_hidden + 53)
+    assert np.abs(torch.nn.functional.linear(torch.from_numpy(v), sd["bias_project.weight"], sd["bias_project.bias"]).numpy()
+                  - (v @ kw["bias_project"][0] + kw["bias_project"][1])).max() < 1e-4
+    # heads: Keras flattens the own-side map (B, 40, 10, K) as [r, c, k]; PyTorch flattens (B, K, 40, 10) as [k, r, c]
+    own = r(2, 40, 10, k)
+    extra = r(2, 53)
+    for layer, prefix in (("policy", "policy_head"), ("value_hidden", "value_head.0"), ("aux_hidden", "aux_head.0")):
+        keras_in = np.concatenate([own.reshape(2, -1), extra], axis=1)
+        torch_in = np.concatenate([own.transpose(0, 3, 1, 2).reshape(2, -1), extra], axis=1)
+        want = keras_in @ kw[layer][0] + kw[layer][1]
+        got = torch.nn.functional.linear(torch.from_numpy(torch_in), sd[prefix + ".weight"], sd[prefix + ".bias"]).numpy()
+        assert np.abs(got - want).max() < 1e-3 * max(1.0, np.abs(want).max()), layer
+    # errors name the layer
+    bad = dict(kw); del bad["value"]
+    with pytest.raises(KeyError, match="value"):
+        nets.port_keras_weights(bad, mc)
+    bad = dict(kw); bad["stem_conv"] = [r(5, 5, 1, f)]
+    with pytest.raises(ValueError, match="stem_conv"):
+        nets.port_keras_weights(bad, mc)
+    # the ported net is a working inference module of this package
+    g, vv = torch.zeros((2, 3, 400)), torch.zeros((3, 105))
+    val, pol = net.evaluate_packed(g, vv)
+    assert val.shape == (3,) and pol.shape == (3, 11583) and abs(float(pol[0].sum()) - 1) < 1e-4

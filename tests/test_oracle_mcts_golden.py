@@ -116,3 +116,21 @@ def test_mcts_tanh_searches(golden_dir):
         assert r["move"] == d["tanh_move"][i] and r["save"] == d["tanh_save"][i]
         assert np.array_equal(r["q"], d["tanh_child_q"][sl]) and np.array_equal(r["p"], d["tanh_child_p"][sl])
         assert d["tanh_child_q"][sl].min() < 0                     # the negative half of the value range is exercised
+
+
+def test_searches_with_the_brute_force_generator(golden_dir):
+    """Config.move_algorithm (ai.py:84, 414): reference searches with 'brute-force' and with 'convolutional' on T-piece
+    positions where the two generators disagree at the root (tests/golden/mcts_bf.npz, oracle/gen_golden_mcts_bf.py)"""
+    d = np.load(os.path.join(golden_dir, "mcts_bf.npz"))
+    off = np.concatenate([[0], np.cumsum(d["child_counts"])])
+    differ = 0
+    for i in range(len(d["states"])):
+        cfg = op.default_mcts_config(max_iter=int(d["max_iter"]), training=0, move_algorithm=int(d["algo"][i]))
+        r = op.mcts_stub(op.OracleGame(state=d["states"][i], seed=int(d["seed"])), cfg)
+        sl = slice(off[i], off[i + 1])
+        assert np.array_equal(r["moves"], d["child_moves"][sl]) and np.array_equal(r["visits"], d["child_visits"][sl]), i
+        assert r["move"] == d["move"][i] and np.array_equal(r["q"], d["child_q"][sl]) and np.array_equal(r["p"], d["child_p"][sl]), i
+        if i % 2 == 1:
+            prev = slice(off[i - 1], off[i])
+            differ += not np.array_equal(d["child_moves"][prev], d["child_moves"][sl])
+    assert differ >= 10                                  # the fixture does tell the two generators apart

@@ -13,8 +13,9 @@ def build(force=False, verbose=False):
 from .selfplay import (Config, SelfPlay, SelfPlayGroups, make_self_play, GameCollector, play_game, make_training_set, self_play_loop,  # noqa: F401,E402
                        instantiate_network, load_best_model, highest_model_number, highest_data_number, search_options,
                        games_from_records)
+from . import nets  # noqa: F401,E402
 from .nets import (AlphaSame, AlphaSameConfig, BaseResNet, BaseResNetConfig, AuxBaseResNet,  # noqa: F401,E402
-                   AuxBaseResNetConfig)
+                   AuxBaseResNetConfig, port_keras_weights)
 from . import compat  # noqa: F401,E402
 from .compat import Game, get_move_matrix, get_move_list, evaluate, MCTS, search_statistics  # noqa: F401,E402
 from . import gating  # noqa: F401,E402

@@ -43,44 +43,17 @@ __global__ __launch_bounds__(BLOCK, 8) void k_legal(trl_game_state *states, uint
 }
 
 // get_move_matrix(player, 'brute-force') -- the reference's default argument (move_generation.py:752); row M6.
-struct BfBlockShared {
-    alignas(16) trl_game_state g;
-    BfScratch mg[2];
-    alignas(4) uint16_t list[2][TRL_MAX_LEGAL];
-    int cnt[2], order, overflow;
-};
 __global__ __launch_bounds__(BLOCK) void k_legal_bruteforce(trl_game_state *states, uint16_t *counts, uint16_t *moves) {
     __shared__ BfBlockShared sh;
-    const int tid = threadIdx.x, game = blockIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, game = blockIdx.x;
     {
         const uint32_t *s = reinterpret_cast<const uint32_t *>(states + game);
         uint32_t *d = reinterpret_cast<uint32_t *>(&sh.g);
         if (tid < STATE_DW) d[tid] = s[tid];
     }
-    if (tid == 0) { sh.overflow = 0; sh.cnt[0] = 0; sh.cnt[1] = 0; sh.order = 0; }
     __syncthreads();
-    const trl_game_state &g = sh.g;
-    if (!is_terminal(g) && !no_move(g)) {
-        const trl_player_state &p = g.p[g.turn];
-        int t0, t1;
-        movegen_types(p, &t0, &t1);
-        const int type = wave == 0 ? t0 : t1;
-        if (type != P_NONE) {
-            int ovf = 0;
-            int n = movegen_bruteforce_wave(p.rows, type, wave == 1, sh.mg[wave], sh.list[wave], TRL_MAX_LEGAL, lane, &ovf);
-            if (lane == 0) { sh.cnt[wave] = n; if (ovf) sh.overflow = 1; }
-        }
-        if (tid == 0) {
-            int b0 = t0 != P_NONE ? C_PLANE_BASE[t0] : 99, b1 = t1 != P_NONE ? C_PLANE_BASE[t1] : 99;
-            sh.order = b1 < b0 ? 1 : 0;
-        }
-    }
-    __syncthreads();
-    int total = sh.cnt[0] + sh.cnt[1];
-    if (total > TRL_MAX_LEGAL) { total = TRL_MAX_LEGAL; if (tid == 0) sh.overflow = 1; }
-    const int a = sh.order, na = sh.cnt[a];
-    for (int i = tid; i < total; i += BLOCK)
-        moves[(size_t)game * TRL_MAX_LEGAL + i] = i < na ? sh.list[a][i] : sh.list[1 - a][i - na];
+    const int total = block_movegen(sh, tid);
+    for (int i = tid; i < total; i += BLOCK) moves[(size_t)game * TRL_MAX_LEGAL + i] = merged_move(sh, i);
     if (tid == 0) {
         counts[game] = (uint16_t)total;
         if (sh.overflow) states[game].flags |= TRL_FLAG_OVERFLOW;

@@ -69,6 +69,44 @@ __device__ __forceinline__ uint16_t merged_move(const BlockShared &sh, int i) {
     return i < na ? sh.list[a][i] : sh.list[1 - a][i - na];
 }
 
+// the same with the reference's default generator, 'brute-force' (move_generation.py:204-243; row M6): k_legal_bruteforce
+// and the search when Config.move_algorithm says so (ai.py:84, 414).  48 KB of LDS per workgroup (the cell-by-cell queue).
+struct BfBlockShared {
+    alignas(16) trl_game_state g;
+    BfScratch mg[2];
+    alignas(4) uint16_t list[2][TRL_MAX_LEGAL];
+    int cnt[2], order, overflow;
+};
+static __device__ __forceinline__ int block_movegen(BfBlockShared &sh, int tid) {
+    const int wave = tid >> 6, lane = tid & 63;
+    if (tid == 0) { sh.overflow = 0; sh.cnt[0] = 0; sh.cnt[1] = 0; sh.order = 0; }
+    __syncthreads();
+    const trl_game_state &g = sh.g;
+    if (!is_terminal(g) && !no_move(g)) {
+        const trl_player_state &p = g.p[g.turn];
+        int t0, t1;
+        movegen_types(p, &t0, &t1);
+        const int type = wave == 0 ? t0 : t1;
+        if (type != P_NONE) {
+            int ovf = 0;
+            int n = movegen_bruteforce_wave(p.rows, type, wave == 1, sh.mg[wave], sh.list[wave], TRL_MAX_LEGAL, lane, &ovf);
+            if (lane == 0) { sh.cnt[wave] = n; if (ovf) sh.overflow = 1; }
+        }
+        if (tid == 0) {
+            int b0 = t0 != P_NONE ? C_PLANE_BASE[t0] : 99, b1 = t1 != P_NONE ? C_PLANE_BASE[t1] : 99;
+            sh.order = b1 < b0 ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    int total = sh.cnt[0] + sh.cnt[1];
+    if (total > TRL_MAX_LEGAL) { total = TRL_MAX_LEGAL; if (tid == 0) sh.overflow = 1; }
+    return total;
+}
+__device__ __forceinline__ uint16_t merged_move(const BfBlockShared &sh, int i) {
+    int a = sh.order, na = sh.cnt[a];
+    return i < na ? sh.list[a][i] : sh.list[1 - a][i - na];
+}
+
 
 }  // namespace trl
 

@@ -112,12 +112,13 @@ __device__ __forceinline__ double np_sum(const double *a, int n) {              
 }
 
 // ---- shared memory of the two kernels ---------------------------------------------------------------
-struct SelectShared {
-    BlockShared b;
+template <class BLK> struct SelectSharedT {     // BLK = BlockShared ('convolutional') or BfBlockShared ('brute-force')
+    BLK b;
     SlotCtl ctl;
     double red_s[2]; int red_k[2];
     int node;
 };
+using SelectShared = SelectSharedT<BlockShared>;
 struct ExpandShared {
     alignas(16) trl_game_state g;
     SlotCtl ctl;
@@ -149,7 +150,8 @@ __device__ unsigned long long g_mprof[16];     // [0..4] k_select phases, [8..12
 // ---- tick part A --------------------------------------------------------------------------------------
 // do_legal = 0: the legal-move search of the leaf is left to k_leaf_legal, which runs beside the net's tower on a second
 // stream (the tower needs the leaf's boards only); leaf_nlegal is filled in there.
-static __device__ __forceinline__ void select_body(SelectShared &sh, const DevMcts &M, trl_game_state *real, float *grids, float *vec,
+template <class SH>
+static __device__ __forceinline__ void select_body(SH &sh, const DevMcts &M, trl_game_state *real, float *grids, float *vec,
                                                    uint8_t *need, int do_legal) {
     const int tid = threadIdx.x, slot = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t nb = (size_t)slot * M.max_nodes;
@@ -344,6 +346,12 @@ __global__ __launch_bounds__(BLOCK) void k_select(DevMcts M, trl_game_state *rea
                                                   int do_legal) {
     __shared__ SelectShared sh;
     select_body(sh, M, real, grids, vec, need, do_legal);
+}
+// Config.move_algorithm = 'brute-force' (ai.py:84, 414): the leaf's legal moves from the reference's cell-by-cell generator.
+// Its own kernel, so that the default one keeps its 10 KB of LDS; not part of the fused expand + select launch.
+__global__ __launch_bounds__(BLOCK) void k_select_bf(DevMcts M, trl_game_state *real, float *grids, float *vec, uint8_t *need) {
+    __shared__ SelectSharedT<BfBlockShared> sh;
+    select_body(sh, M, real, grids, vec, need, 1);
 }
 
 // the legal-move search of every slot's current leaf (get_move_matrix + get_move_list, ai.py:414-417), split off k_select:
@@ -974,6 +982,8 @@ extern "C" {
 
 int trl_mcts_create(trl_engine *h, const trl_mcts_config *cfg) {
     if (!h || !cfg || cfg->max_iter <= 0) return fail(TRL_E_INVALID, "trl_mcts_create: %s", "bad argument");
+    if (cfg->move_algorithm != TRL_ALGO_CONVOLUTIONAL && cfg->move_algorithm != TRL_ALGO_BRUTE_FORCE)
+        return fail(TRL_E_INVALID, "trl_mcts_create: %s", "Unknown algorithm (the lossy generators 'faster-but-loss' / 'harddrop' are not built)");
     if (!h->have_reset) return fail(TRL_E_STATE, "%s", "trl_mcts_create before trl_env_reset / trl_env_set_state");
     HIPCHK(hipSetDevice(h->cfg.device));
     trl_mcts_free_internal(h);
@@ -1027,6 +1037,12 @@ int trl_mcts_select_need(trl_engine *h, float *dev_grids, float *dev_vec, uint8_
     HIPCHK(hipSetDevice(h->cfg.device));
     trl_mcts *m = h->mcts;
     const int fork = m->fork_legal && dev_need;         // only the tower-need flow has something to overlap with
+    if (m->d.cfg.move_algorithm == TRL_ALGO_BRUTE_FORCE) {
+        if (fork) return fail(TRL_E_STATE, "%s", "trl_mcts_fork_legal: not with move_algorithm = brute-force");
+        hipLaunchKernelGGL(k_select_bf, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, m->d, h->d_states, dev_grids, dev_vec, dev_need);
+        HIPCHK(hipGetLastError());
+        return TRL_OK;
+    }
     hipLaunchKernelGGL(k_select, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, m->d, h->d_states, dev_grids, dev_vec, dev_need,
                        fork ? 0 : 1);
     HIPCHK(hipGetLastError());
@@ -1139,6 +1155,8 @@ int trl_mcts_expand_alphasame_select(trl_engine *h, const float *dev_z, float *d
     HIPCHK(hipSetDevice(h->cfg.device));
     if (h->mcts->d.zdim != 400) return fail(TRL_E_STATE, "%s", "trl_mcts_expand_alphasame_select needs the 400-float tower cache (trl_mcts_zcache_dim)");
     if (h->mcts->fork_legal) return fail(TRL_E_STATE, "%s", "trl_mcts_expand_alphasame_select: not with trl_mcts_fork_legal");
+    if (h->mcts->d.cfg.move_algorithm != TRL_ALGO_CONVOLUTIONAL)
+        return fail(TRL_E_STATE, "%s", "trl_mcts_expand_alphasame_select: the fused launch runs the 'convolutional' generator only");
     HeadsDev H{w->oside_w, w->oside_b, w->value0_w, w->value0_b, w->value3_w, w->value3_b, w->use_tanh, nullptr, 0};
     hipLaunchKernelGGL(k_expand_select, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_vec,
                        dev_z, w->policy_w, w->policy_b, H, dev_grids, dev_need);

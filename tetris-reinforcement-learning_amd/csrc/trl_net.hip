@@ -311,8 +311,13 @@ __device__ __forceinline__ unsigned lo_pair(unsigned hpair, float a2, float b2) 
 // value of 65 520 or more has no f16 hi half (it rounds to infinity and the convolution that reads it returns inf / NaN,
 // which the next ReLU may even turn into a plausible 0): the kernels report it through g_split_overflow instead of
 // returning such numbers silently (trl_tower_overflow; nets.py re-runs the board on the fp32 kernels).
+#ifndef TRL_RANGE_GUARD
+#define TRL_RANGE_GUARD 1       // 0: timing experiment only (scripts/guard_ab.py) -- the kernels then return inf / NaN silently
+#endif
 __device__ __forceinline__ void store_split4(_Float16 *hi, _Float16 *lo, int idx, f32x4 v, float &mx) {
+#if TRL_RANGE_GUARD
     mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+#endif
     const f16x4 h = __builtin_convertvector(v, f16x4);                  // 2 x v_cvt_pk_f16_f32 (round to nearest even)
     const f32x4 v2 = v * SPLIT;
     const uint2 hp = __builtin_bit_cast(uint2, h);

@@ -40,7 +40,7 @@ class TrlMctsConfig(C.Structure):
                 ("use_dir_s", C.c_int32), ("use_forced", C.c_int32), ("save_all", C.c_int32),
                 ("max_nodes", C.c_int32), ("record_capacity", C.c_int32), ("auto_reset", C.c_int32),
                 ("use_tanh", C.c_int32), ("random_start", C.c_int32), ("episodes_base", C.c_int32),
-                ("episodes_extra", C.c_int32), ("cpuct", C.c_double), ("dpuct", C.c_double), ("fpu_value", C.c_double),
+                ("episodes_extra", C.c_int32), ("move_algorithm", C.c_int32), ("reserved0", C.c_int32), ("cpuct", C.c_double), ("dpuct", C.c_double), ("fpu_value", C.c_double),
                 ("root_softmax_temp", C.c_double), ("temperature", C.c_double),
                 ("playout_cap_chance", C.c_double), ("playout_cap_mult", C.c_double),
                 ("dir_alpha", C.c_double), ("dir_s", C.c_double), ("dir_expl", C.c_double), ("c_forced", C.c_double)]
@@ -49,7 +49,7 @@ class TrlMctsConfig(C.Structure):
 def mcts_config(**kw):
     c = TrlMctsConfig(max_iter=400, training=0, fpu_reduction=1, use_root_softmax=1, use_playout_cap=1,
                       use_dirichlet=1, use_dir_s=1, use_forced=0, save_all=0, max_nodes=0, record_capacity=0,
-                      auto_reset=1, use_tanh=0, random_start=0, episodes_base=0, episodes_extra=0, cpuct=0.75, dpuct=1.0, fpu_value=0.1, root_softmax_temp=1.1, temperature=0.1,
+                      auto_reset=1, use_tanh=0, random_start=0, episodes_base=0, episodes_extra=0, move_algorithm=0, reserved0=0, cpuct=0.75, dpuct=1.0, fpu_value=0.1, root_softmax_temp=1.1, temperature=0.1,
                       playout_cap_chance=0.25, playout_cap_mult=5.0, dir_alpha=0.1, dir_s=25.0, dir_expl=0.25,
                       c_forced=1.0)
     for k, v in kw.items():

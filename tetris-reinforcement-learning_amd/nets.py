@@ -634,3 +634,69 @@ class AuxBaseResNet(BaseResNet):
         aux = torch.sigmoid(F.linear(torch.relu(F.linear(hx, *fd["a0"])), self.aux_head["3"].weight, self.aux_head["3"].bias))
         v = torch.tanh(v) if self.use_tanh else torch.sigmoid(v)
         return v.reshape(-1, 1), logits, aux
+
+
+# ---- Keras -> PyTorch weight layout of the default family (util.py:2369-2464) ------------------------------------------
+# The reference's current default configuration trains with Keras and stores `.keras` checkpoints; its
+# port_keras_auxbaseresnet_to_pytorch names every weight-bearing Keras layer after the PyTorch state_dict prefix it
+# feeds.  Keras is not importable in this build's environment, so the port takes the weights as plain arrays
+# (layer name -> keras_layer.get_weights()) -- what `{l.name: l.get_weights() for l in keras_model.layers}` gives where
+# Keras exists.  PARITY UNPINNED: no Keras output can be produced here to compare with; the layout rules below are the
+# reference's (kernels HWIO -> OIHW, Dense (in, out) -> (out, in), BatchNormalization [gamma, beta, mean, var], and the
+# NHWC flatten order of the own-side map in front of the three heads), checked by a synthetic forward-equivalence test.
+def _keras_layer_table(blocks):
+    """(keras layer name, state_dict prefix, kind) in the order of the reference's port"""
+    t = [("stem_conv", "stem.0", "conv"), ("stem_bn", "stem.1", "bn")]
+    for i in range(blocks):
+        t += [("block%d_conv1" % i, "trunk.%d.conv1" % i, "conv"), ("block%d_bn1" % i, "trunk.%d.bn1" % i, "bn"),
+              ("block%d_conv2" % i, "trunk.%d.conv2" % i, "conv"), ("block%d_bn2" % i, "trunk.%d.bn2" % i, "bn")]
+    t += [("opp_collapse_conv", "opp_collapse.0", "conv"), ("opp_collapse_bn", "opp_collapse.1", "bn"),
+          ("opp_encode_dense", "opp_encode.0", "dense"), ("opp_encode_bn", "opp_encode.1", "bn"),
+          ("bias_project", "bias_project", "dense"),
+          ("own_collapse_conv", "own_collapse.0", "conv"), ("own_collapse_bn", "own_collapse.1", "bn"),
+          ("policy", "policy_head", "head"),
+          ("value_hidden", "value_head.0", "head"), ("value_hidden_bn", "value_head.1", "bn"), ("value", "value_head.3", "dense"),
+          ("aux_hidden", "aux_head.0", "head"), ("aux_hidden_bn", "aux_head.1", "bn"), ("aux", "aux_head.3", "dense")]
+    return t
+
+
+def port_keras_weights(keras_weights, model_config=None, use_tanh=False, aux=True):
+    """keras_weights: {layer name: [arrays as keras_layer.get_weights() returns them]} of a Keras AuxBaseResNet (or
+    BaseResNet with aux=False) built by the reference's gen_auxbaseresnet_keras -> the PyTorch-layout net of this package
+    with those weights (eval mode, CPU).  Raises KeyError for a missing layer and ValueError for a shape that does not
+    fit, naming the layer."""
+    import numpy as np
+    mc = model_config or (AuxBaseResNetConfig() if aux else BaseResNetConfig())
+    net = AuxBaseResNet(mc, use_tanh) if aux else BaseResNet(mc, use_tanh)
+    sd = net.state_dict()
+    k = mc.own_kernels
+    flat = k * ROWS * COLS
+
+    def put(key, arr, layer):
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        if tuple(sd[key].shape) != arr.shape:
+            raise ValueError("Keras layer %r: %s has shape %s, the PyTorch parameter %s" % (layer, key, arr.shape, tuple(sd[key].shape)))
+        sd[key] = torch.from_numpy(arr.copy())
+
+    for layer, prefix, kind in _keras_layer_table(mc.blocks):
+        if not aux and prefix.startswith("aux_head"):
+            continue
+        if layer not in keras_weights:
+            raise KeyError("Keras layer %r (-> %s) is missing" % (layer, prefix))
+        w = [np.asarray(a) for a in keras_weights[layer]]
+        if kind == "conv":                                  # Conv2D kernel (kH, kW, in, out), no bias
+            put(prefix + ".weight", w[0].transpose(3, 2, 0, 1), layer)
+        elif kind == "bn":                                  # [gamma, beta, moving_mean, moving_variance]
+            for name, a in zip(("weight", "bias", "running_mean", "running_var"), w):
+                put("%s.%s" % (prefix, name), a, layer)
+        else:                                               # Dense kernel (in, out), bias (out,)
+            kern = w[0]
+            if kind == "head":
+                # Keras flattens the own-side map (B, ROWS, COLS, K) in [r, c, k] order, PyTorch's flatten(1) of
+                # (B, K, ROWS, COLS) in [k, r, c] order: re-order the first K * ROWS * COLS input rows, keep the rest
+                own = kern[:flat].reshape(ROWS, COLS, k, -1).transpose(2, 0, 1, 3).reshape(flat, -1)
+                kern = np.concatenate([own, kern[flat:]], axis=0)
+            put(prefix + ".weight", kern.T, layer)
+            put(prefix + ".bias", w[1], layer)
+    net.load_state_dict(sd)
+    return net.eval()

@@ -83,9 +83,9 @@ class Config:
 
 def search_options(config, **extra):
     """Config -> trl_mcts_config"""
-    if config.move_algorithm != "convolutional":
-        raise ValueError("Unknown algorithm: %s (the search runs the reference default 'convolutional'; 'brute-force' is "
-                         "available through get_move_matrix)" % config.move_algorithm)
+    if config.move_algorithm not in _eng.MOVE_ALGORITHMS:      # the reference raises the same for a name it does not know
+        raise ValueError("Unknown algorithm: %s (the lossy generators 'faster-but-loss' / 'harddrop' are not built)"
+                         % config.move_algorithm)
     if config.FpuStrategy not in ("reduction", "absolute"):
         raise ValueError("Unknown FpuStrategy: %s" % config.FpuStrategy)
     opts = dict(max_iter=int(config.MAX_ITER), training=int(bool(config.training)),
@@ -94,7 +94,8 @@ def search_options(config, **extra):
                 use_dirichlet=int(bool(config.use_dirichlet_noise)), use_dir_s=int(bool(config.use_dirichlet_s)),
                 use_forced=int(bool(config.use_forced_playouts_and_policy_target_pruning)),
                 save_all=int(bool(config.save_all)), use_tanh=int(bool(config.use_tanh)),
-                random_start=int(bool(config.use_random_starting_moves)), cpuct=float(config.CPUCT), dpuct=float(config.DPUCT),
+                random_start=int(bool(config.use_random_starting_moves)),
+                move_algorithm=_eng.MOVE_ALGORITHMS[config.move_algorithm], cpuct=float(config.CPUCT), dpuct=float(config.DPUCT),
                 fpu_value=float(config.FpuValue), root_softmax_temp=float(config.RootSoftmaxTemp),
                 temperature=float(config.temperature), playout_cap_chance=float(config.playout_cap_chance),
                 playout_cap_mult=float(config.playout_cap_mult), dir_alpha=float(config.DIRICHLET_ALPHA),
@@ -215,7 +216,7 @@ class SelfPlay:
             # the tick is library kernels only: capture it with the library's own HIP graph (trl_graph_*); a
             # torch.cuda.CUDAGraph replay adds half a dozen small generator-state kernels of its own per replay
             with torch.cuda.stream(self.stream):
-                if FUSE_SELECT and not self.fork_legal:
+                if FUSE_SELECT and not self.fork_legal and self.config.move_algorithm == "convolutional":
                     # expand of one simulation and select of the next in one launch (trl_mcts_expand_alphasame_select):
                     # the first selection is made here, every tick after it is {tower, expand + select}
                     self.engine.mcts_select_need(self.grids.data_ptr(), self.vec.data_ptr(), self.need.data_ptr())
