@@ -410,7 +410,8 @@ int  trl_resnet_trunk(const float *dev_boards, int n_boards, const float *dev_pa
 /* Range guard of the split towers (trl_alphasame_trunk16_split, trl_trunk_wide_split).  They split every activation into
  * two f16 halves; an activation of 65 504 or more has no finite hi half and the board's output would be built on inf / NaN
  * (the folded conv WEIGHTS are range-checked on the host when they are packed, activations can only be checked here).
- * *count_out = boards, since the last reset, in which that happened on HIP device `device`; reset != 0 clears the count.
+ * *count_out = 0 if that has not happened on HIP device `device` since the last reset, else the number of wavefronts (4
+ * or 8 per board) that saw it; reset != 0 clears the count.
  * The caller synchronises the stream(s) its towers ran on first.  A caller that sees a count > 0 runs those boards again
  * on the fp32 towers (trl_alphasame_trunk / trl_resnet_trunk), which have no such limit -- nets.AlphaSame.trunk() does.    */
 int  trl_tower_overflow(int device, int reset, uint32_t *count_out);

@@ -570,7 +570,7 @@ def test_activations_outside_the_split_range_are_reported_and_recomputed(golden_
     trl.engine.tower_overflow(0)
     hot._trunk_hip(tg.reshape(-1, 1, 40, 10), hot._folded["packed_tower"])
     torch.cuda.synchronize()
-    assert 8 <= trl.engine.tower_overflow(0) <= 2 * len(d["states"])                  # one count per board (nearly all of them here)
+    assert 8 <= trl.engine.tower_overflow(0) <= 4 * 2 * len(d["states"])              # counted per wavefront: up to 4 per board
     assert trl.engine.tower_overflow(0) == 0                                           # reading resets
     with pytest.warns(trl.nets.SplitActivationRange):
         v, logits = hot.heads(tg, tv)

@@ -30,7 +30,7 @@ constexpr int SPAWN_Y = TRL_ROWS - TRL_SPAWN_ROW;   // 17
 // puts a cell outside the 40 rows) and visited / present bits are subsets of valid ones, so the two rows before and
 // after valid[r] -- the end of visited[3] or valid[r-1], the start of valid[r+1] or present[0] -- are zero guard rows:
 // the kick probes read valid[r][y] for y in [-2, 45] without clamping or bounds tests.
-struct alignas(4) MgScratch {
+struct alignas(8) MgScratch {
     uint16_t visited[4][MAP_H];
     uint16_t valid[4][MAP_H];      // valid[r][ym] bit xm: piece (rotation r) at origin (xm-2, ym-2) fits; bits 14, 15 zero
     uint16_t present[4][MAP_H];    // unflagged placements
@@ -211,7 +211,7 @@ static __device__ __forceinline__ int placements_to_moves(const SCR &S, int type
 // hold / next (Player.create_piece must succeed, player.py:37-44).  Writes the encoded
 // placements of this piece type in ascending order to out[] and returns their number;
 // *overflow is set when a cap was hit.
-static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int type, bool need_spawn, MgScratch &S,
+static __device__ __forceinline__ int movegen_ordered_wave(const uint16_t *rows, int type, bool need_spawn, MgScratch &S,
                             uint16_t *out, int out_cap, int lane, int *overflow) {
 #ifdef TRL_PROFILE
     unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -378,6 +378,182 @@ static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int typ
     if (lane == 0) for (int i = 0; i < 12; i++) atomicAdd(&g_prof[i], prof_acc[i]);
 #endif
     return total;
+}
+
+// ---- the same search as a closure on column masks (round 3) ---------------------------------------------------------
+// The reference's generator is a FIFO walk, but for every piece other than T its RESULT does not depend on the walk's
+// order: the visited set is the closure of the start cell under {left, right, down} inside a rotation state
+// (move_generation.py:409-425, 485-488) and under the kick edges of EDGE cells (:427-481) -- a static graph: which kick of a
+// list fits a cell first, and where it lands, depends on the validity maps only -- and the placements are its cells that
+// cannot move down (:439-440).  For T the order decides one thing: the sub-plane of a stuck cell whose flagged arrivals came
+// BOTH through the last kick of a list and through another kick (the last flagged writer wins, :671-677).  A T search with
+// no such cell is order-free as well; one with such a cell takes the ordered walk above (`*need_ordered`; 21 % of the T
+// searches of the fixture games, 3 % of all searches).  scripts/bfs_closure_proto.py states this in Python and checks it
+// against the reference's lists (0 differences on 1 884 + 360 fixture searches outside those T cases).
+//
+// Layout: one lane per (rotation, map column): rot = lane >> 4, mx = lane & 15 (14 columns; lanes 14, 15 of a row idle);
+// a lane holds 64-bit COLUMN masks over the 44 map rows.  "Down" is a carry chain (one add), left / right are DPP row
+// shifts by one lane, so one step of the fixed point is ~20 vector instructions for all four rotations at once and touches
+// no memory; kicks go through LDS (read the target column's validity, OR the arrivals into the target lane's word).
+// The ordered walk needs 2 700 vector instructions and 376 dependent LDS round trips per search; this one ~1 200 and ~40.
+struct alignas(8) CsScratch {
+    uint16_t present[4][MAP_H];      // the three planes placements_to_moves reads (same names as MgScratch)
+    uint16_t flagp[4][MAP_H];
+    uint16_t ulp[4][MAP_H];
+    uint64_t fcol[20];               // free cells of board column x (bit = map row) at index x + 2, zero elsewhere
+    uint64_t vcol[4 * 20];           // valid[rot] column mx at index rot * 20 + mx + 2; the other entries are zero guards
+    uint64_t arr[2][4 * 20];         // kick arrivals, same indexing: [1] through the last kick of a list (T, not 180), [0] others
+};
+static_assert(sizeof(CsScratch) <= sizeof(MgScratch), "the closure search's scratch shares the ordered walk's memory");
+
+__device__ __forceinline__ uint64_t dpp64(uint64_t v, const int ctrl_is_shl) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    if (ctrl_is_shl) {      // row_shl:1 -- lane i takes lane i + 1 of its row of 16 (zero at the end of the row)
+        lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x101, 0xf, 0xf, false);
+        hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x101, 0xf, 0xf, false);
+    } else {                // row_shr:1 -- lane i takes lane i - 1
+        lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)lo, 0x111, 0xf, 0xf, false);
+        hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hi, 0x111, 0xf, 0xf, false);
+    }
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// column mask -> one bit per set row in a plane of row masks (LDS atomics on the 32-bit words holding two rows)
+__device__ __forceinline__ void scatter_column(uint16_t *plane, uint64_t col, int rot, int mx) {
+    unsigned int *w = reinterpret_cast<unsigned int *>(plane);
+    while (__ballot(col != 0)) {
+        if (col) {
+            const int my = __ffsll((unsigned long long)col) - 1;
+            col &= col - 1;
+            const int idx = rot * MAP_H + my;
+            atomicOr(w + (idx >> 1), (1u << mx) << ((idx & 1) * 16));
+        }
+    }
+}
+
+static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows, int type, bool need_spawn, CsScratch &C,
+                                                           uint16_t *out, int out_cap, int lane, int *overflow, bool *need_ordered) {
+    const int rot = lane >> 4, mx = lane & 15;
+    const bool isT = (type == PT), check_rot = (type != PO);
+    // free cells per board column: ten ballots over the rows (lane = board row), column x kept by lane x + 2
+    const uint32_t myrow = lane < TRL_ROWS ? (uint32_t)rows[lane < TRL_ROWS ? lane : 0] : 0x3FFu;
+    uint64_t mine = 0;
+#pragma unroll
+    for (int x = 0; x < TRL_COLS; x++) {
+        const uint64_t occ = __ballot((myrow >> x) & 1u);
+        const uint64_t fr = (~occ & ((1ull << TRL_ROWS) - 1ull)) << 2;
+        if (lane == x + 2) mine = fr;
+    }
+    if (lane < 20) C.fcol[lane] = mine;
+    {
+        uint32_t *z = reinterpret_cast<uint32_t *>(&C.arr[0][0]);
+        for (int i = lane; i < 2 * 4 * 20 * 2; i += 64) z[i] = 0;
+        uint32_t *pz = reinterpret_cast<uint32_t *>(&C.present[0][0]);
+        for (int i = lane; i < (isT ? 3 : 1) * 4 * MAP_H / 2; i += 64) pz[i] = 0;
+    }
+    // _get_highest_row / _set_starting_position (move_generation.py:164-180)
+    const uint64_t occm = __ballot(lane < TRL_ROWS && myrow != 0);
+    const int highest = occm ? (__ffsll((unsigned long long)occm) - 1) : TRL_ROWS;
+    int sy = highest - C_BOX[type]; if (sy < SPAWN_Y) sy = SPAWN_Y;
+    const int sx = spawn_x(type);
+    wave_sync();
+    // validity of (rot, mx): all four minos on free cells (move_generation.py:490-528), as a column
+    uint64_t valid = (1ull << MAP_H) - 1ull;
+    {
+        const uint32_t m = C_MINO[type * 4 + rot];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int cx = (int)((m >> (4 * i)) & 3), cy = (int)((m >> (4 * i + 2)) & 3);
+            valid &= C.fcol[mx + cx] >> cy;
+        }
+        if (mx >= MAP_W) valid = 0;
+    }
+    C.vcol[rot * 20 + mx + 2] = valid;                      // (mx 14, 15: zeros at 16, 17)
+    if (mx < 2) C.vcol[rot * 20 + mx] = 0;                  // guards 0, 1
+    if (mx >= MAP_W) C.vcol[rot * 20 + mx + 4] = 0;         // guards 18, 19
+    wave_sync();
+    const uint64_t v0 = C.vcol[sx + 2 + 2];                 // rotation 0, column sx + 2
+    bool ok = (v0 >> (sy + 2)) & 1;                                                      // :349-351
+    if (need_spawn) ok = ok && ((v0 >> (SPAWN_Y + 2)) & 1);                              // player.py:40
+    *need_ordered = false;
+    if (!uni(ok)) return 0;
+
+    // edge cells (:427-431): cannot move down, or a side neighbour is not valid.  (valid >> 1: bit my = the cell below is valid)
+    const uint64_t edge = valid & (~(valid >> 1) | ~dpp64(valid, 0) | ~dpp64(valid, 1));
+    const int ktab = (type == PI) ? 12 : 0;
+    uint64_t kt[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) kt[d] = check_rot ? C_KICK[ktab + rot * 3 + d] : 0ull;
+    uint64_t reach = (lane == sx + 2) ? (1ull << (sy + 2)) : 0ull;
+    uint64_t done = 0;
+    for (;;) {
+        // fixed point under down / left / right inside every rotation state
+        for (;;) {
+            const uint64_t old = reach;
+            reach |= ((valid + reach) ^ valid) & valid;                                  // down: carry chain through the valid run
+            reach |= (dpp64(reach, 0) | dpp64(reach, 1)) & valid;                        // one column to either side
+            if (!__ballot(reach != old)) break;
+        }
+        if (!check_rot) break;
+        // kicks of the edge cells that have not sent theirs yet (each cell sends once, like the flood that first visits it)
+        const uint64_t src = reach & edge & ~done;
+        done |= src;
+        if (!__ballot(src != 0)) break;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const int nrot = (rot + d + 1) & 3;
+            const int nk = (int)(kt[d] >> 60);
+            uint64_t rem = src;
+            uint64_t kq = kt[d];
+#pragma unroll 1
+            for (int ki = 0; ki < 6; ki++, kq >>= 6) {
+                if (!__ballot(rem != 0 && ki < nk)) break;
+                const int fx = (int)(kq & 7), fy = (int)((kq >> 3) & 7);                 // kick (fx - 2, fy - 2)
+                const int idx = nrot * 20 + mx + fx;                                     // target column mx + kx, + 2
+                const uint64_t vt = C.vcol[idx];
+                uint64_t fit = (vt << 2) >> (4 - fy);                                    // bit my: the target row my - ky is valid
+                if (ki >= nk) fit = 0;
+                const uint64_t moved = rem & fit;                                        // first fitting kick wins (:452-470)
+                rem &= ~fit;
+                const uint64_t dest = ((moved << 2) >> fy) & ~3ull;                      // rows my - ky; new_y < 0: discarded (:462-463)
+                if (dest) {
+                    const int last = (isT && d != 1 && ki == nk - 1) ? 1 : 0;
+                    atomicOr(reinterpret_cast<unsigned long long *>(&C.arr[last][idx]), (unsigned long long)dest);
+                }
+            }
+        }
+        wave_sync();
+        const uint64_t add = (C.arr[0][rot * 20 + mx + 2] | C.arr[1][rot * 20 + mx + 2]) & ~reach;
+        reach |= add;
+        if (!__ballot(add != 0)) break;
+    }
+    // placements: cells that cannot move down (:439-440); T: flagged arrivals on such cells (:386-392, 474-480)
+    const uint64_t stuck = valid & ~(valid >> 1);
+    if (isT) {
+        const uint64_t f1 = C.arr[1][rot * 20 + mx + 2] & stuck, f0 = C.arr[0][rot * 20 + mx + 2] & stuck;
+        if (__ballot((f1 & f0) != 0)) { *need_ordered = true; return 0; }               // the walk's order decides: take it
+        scatter_column(&C.flagp[0][0], f1 | f0, rot, mx);
+        scatter_column(&C.ulp[0][0], f1, rot, mx);
+    }
+    scatter_column(&C.present[0][0], reach & stuck, rot, mx);
+    wave_sync();
+    int total = placements_to_moves(C, type, out, out_cap, lane);
+    if (total > out_cap) { *overflow = 1; total = out_cap; }
+    wave_sync();
+    return total;
+}
+
+#ifndef TRL_CLOSURE
+#define TRL_CLOSURE 1       // 0: every search takes the ordered walk (A/B builds)
+#endif
+static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int type, bool need_spawn, MgScratch &S,
+                                                   uint16_t *out, int out_cap, int lane, int *overflow) {
+#if TRL_CLOSURE
+    bool ordered = false;
+    const int n = movegen_closure_wave(rows, type, need_spawn, reinterpret_cast<CsScratch &>(S), out, out_cap, lane, overflow, &ordered);
+    if (!ordered) return n;
+#endif
+    return movegen_ordered_wave(rows, type, need_spawn, S, out, out_cap, lane, overflow);
 }
 
 // ---- the reference's default generator, 'brute-force' (move_generation.py:204-243) ------------------------------

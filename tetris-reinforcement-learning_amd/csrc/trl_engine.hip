@@ -72,7 +72,13 @@ __global__ __launch_bounds__(BLOCK) void k_step(trl_game_state *states, const ui
         int total = block_movegen(sh, tid);
         bool mine = false;
         for (int i = tid; i < total; i += BLOCK) mine |= (merged_move(sh, i) == move);
-        legal = __syncthreads_or(mine);
+        // (an explicit flag, not __syncthreads_or: the device library's workgroup reduction returned 0 for a set predicate in
+        // a few of 8 092 workgroups per launch once the two waves' searches finished far apart)
+        if (tid == 0) sh.done = 0;
+        __syncthreads();
+        if (mine) sh.done = 1;
+        __syncthreads();
+        legal = sh.done != 0;
     }
     if (tid < 64) {
         if (legal) make_move(sh.g, seed, move, add_bag != 0, tid);

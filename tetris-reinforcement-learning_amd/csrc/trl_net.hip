@@ -288,11 +288,13 @@ constexpr float SPLIT = 2048.f, INV_SPLIT = 1.f / 2048.f;
 
 using f16x4 = __attribute__((ext_vector_type(4))) _Float16;
 
-// workgroups (boards) of the split towers whose activations left the f16 range since the counter was last reset
+// wavefronts of the split towers whose activations left the f16 range since the counter was last reset (0 = none did)
 __device__ unsigned int g_split_overflow;
 constexpr float SPLIT_ACT_MAX = 65504.f;         // largest finite f16
-__device__ __forceinline__ void report_split_range(float mx) {      // all threads of the workgroup, once, after the last conv
-    if (__syncthreads_or(mx >= SPLIT_ACT_MAX) && threadIdx.x == 0) atomicAdd(&g_split_overflow, 1u);
+// (per wave: a board whose four or eight waves all overflow counts that often -- the callers only ask "zero or not"; the
+// library's workgroup reduction __syncthreads_or is avoided: in k_step it returned 0 for a set predicate now and then)
+__device__ __forceinline__ void report_split_range(float mx) {
+    if (__any(mx >= SPLIT_ACT_MAX) && (threadIdx.x & 63) == 0) atomicAdd(&g_split_overflow, 1u);
 }
 
 // four values (the lane's four channels of one position) -> hi and lo halves, one 8-byte store each.
