@@ -173,7 +173,7 @@ def test_slot_groups_play_the_same_games():
     kw = dict(seed=21, streams=streams, auto_reset=True, episodes=(1, 40))       # slots 0..39 play two games, the rest one
     one = trl.SelfPlay(cfg, net, 64, **kw)
     two = trl.SelfPlayGroups(cfg, net, 64, 2, **kw)
-    assert [p.n for p in two.parts] == [32, 32] and selfplay.slot_groups(cfg, net, 1024) == 2 and selfplay.slot_groups(cfg, net, 64) == 1
+    assert [p.n for p in two.parts] == [32, 32] and selfplay.slot_groups(cfg, net, 1024) == 4 and selfplay.slot_groups(cfg, net, 512) == 2 and selfplay.slot_groups(cfg, net, 64) == 1
     got = []
     for sp in (one, two):
         recs = []
@@ -596,8 +596,8 @@ def _sorted_records(sp):
 
 def test_production_tick_at_c3_size(monkeypatch):
     """BASELINE config C3 as the bench times it -- 1024 slots, AlphaSame(10, 16) on k_trunk16s, training=True, the fused
-    expand + select launch inside eight-tick graphs, two slot groups on two streams -- for 480 ticks, against the same
-    job run as one group, with the three-kernel tick (TRL_FUSE_SELECT=0) and with one tick per graph (TRL_GRAPH_TICKS=1):
+    expand + select launch inside eight-tick graphs, four slot groups on four streams -- for 480 ticks, against the same
+    job run as two groups and as one group, with the three-kernel tick (TRL_FUSE_SELECT=0) and with one tick per graph (TRL_GRAPH_TICKS=1):
     identical records, no overflow of any kind, and the invariants of a search (ai.py:299-659) on every record."""
     from tetris_rl_amd import selfplay
     torch.manual_seed(0)
@@ -606,7 +606,7 @@ def test_production_tick_at_c3_size(monkeypatch):
     cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=160, training=True)
     n, ticks, seed = 1024, 480, 20260630
     out = []
-    for groups, fuse, per_graph in ((2, True, 8), (1, True, 8), (1, False, 8), (1, True, 1)):
+    for groups, fuse, per_graph in ((4, True, 8), (2, True, 8), (1, True, 8), (1, False, 8), (1, True, 1)):
         monkeypatch.setattr(selfplay, "FUSE_SELECT", fuse)
         monkeypatch.setattr(selfplay, "GRAPH_TICKS", per_graph)
         kw = dict(seed=seed, auto_reset=True, record_capacity=1 << 15)

@@ -141,7 +141,9 @@ __device__ __forceinline__ void copy_state(trl_game_state *dst, const trl_game_s
 #ifdef TRL_PROFILE
 __device__ unsigned long long g_mprof[16];     // [0..4] k_select phases, [8..12] k_expand phases, cycles summed over slots
 #define MPROF_T(v) unsigned long long v = __builtin_readcyclecounter()
-#define MPROF_ADD(i, a, b) do { if (threadIdx.x == 0) atomicAdd(&g_mprof[i], (unsigned long long)((b) - (a))); } while (0)
+__device__ unsigned int g_slotprof[4096 * 16];  // the same per slot, for the last launch: the slowest slots set a launch's length
+#define MPROF_ADD(i, a, b) do { if (threadIdx.x == 0) { atomicAdd(&g_mprof[i], (unsigned long long)((b) - (a))); \
+                                if (blockIdx.x < 4096) g_slotprof[blockIdx.x * 16 + (i)] = (unsigned int)((b) - (a)); } } while (0)
 #else
 #define MPROF_T(v)
 #define MPROF_ADD(i, a, b)
@@ -1242,6 +1244,10 @@ int trl_mcts_root_children(trl_engine *h, int32_t *counts, uint16_t *moves, int3
 // test hook: the stub evaluator on the current leaves (values[n], policy[n][11583], device pointers)
 int trl_debug_stub_eval_salted(trl_engine *h, float *dev_values, float *dev_policy, uint64_t salt);
 #ifdef TRL_PROFILE
+int trl_debug_mcts_slotprof(unsigned int *host_out, int n_slots) {
+    HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_slotprof), sizeof(unsigned int) * 16 * (size_t)n_slots));
+    return TRL_OK;
+}
 int trl_debug_mcts_prof(unsigned long long *host_out, int reset) {
     HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_mprof), sizeof(unsigned long long) * 16));
     if (reset) { unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_mprof), z, sizeof z)); }

@@ -129,7 +129,7 @@ class SelfPlay:
 
     def __init__(self, config, network, n_slots, seed=0, device=0, streams=None, auto_reset=True, use_graph=True,
                  max_nodes=0, record_capacity=0, policy_head="legal", tower_cache=True, device_heads=True, episodes=(0, 0),
-                 fork_legal=None):
+                 fork_legal=None, hip_stream=None):
         """policy_head: "legal" = only the legal moves' logits are formed, inside the expand kernel
         (trl_mcts_expand_head); "full" = the reference's data flow, softmax over all 11 583 logits."""
         if policy_head not in ("legal", "full"):
@@ -143,7 +143,7 @@ class SelfPlay:
         torch.cuda.set_device(self.device)
         self.net = network.to(self.device).prepare()
         self.n = int(n_slots)
-        self.stream = torch.cuda.Stream(device=self.device)
+        self.stream = hip_stream if hip_stream is not None else torch.cuda.Stream(device=self.device)
         self.engine = _eng.Engine(self.n, ruleset=config.ruleset, seed=seed, device=device, stream=self.stream.cuda_stream)
         self.engine.reset(streams)
         # episodes = (base, extra): slot s plays base + (s < extra) games, then idles (0, 0: no limit)
@@ -302,6 +302,44 @@ class SelfPlay:
         return st
 
 
+def concurrent_streams(torch, device, count, spin_ms=0.4, tries=24):
+    """`count` HIP streams of `device` on which kernels really run side by side.  The runtime maps streams onto a few
+    hardware queues (4 by default) by an internal least-used rule; two streams that land on one queue execute their
+    kernels one after the other, and slot groups ticking on such a pair lose everything the grouping is for (C3 with four
+    groups: 0.25 ms per round instead of 0.16, about one process in three).  So: take streams from torch's pool one by one
+    and keep a candidate only if a spin kernel on it overlaps a spin kernel on every stream kept so far."""
+    import time
+    cycles = int(spin_ms * 2.0e6)                       # ~2 GHz: a spin of spin_ms
+    kept, rejected = [], []
+
+    def overlaps(a, b):
+        for s in (a, b):
+            s.synchronize()
+        t0 = time.perf_counter()
+        for s in (a, b):
+            with torch.cuda.stream(s):
+                torch.cuda._sleep(cycles)
+        for s in (a, b):
+            s.synchronize()
+        both = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(cycles)
+        a.synchronize()
+        one = time.perf_counter() - t0
+        return both < 1.5 * one
+
+    with torch.cuda.device(device):
+        torch.cuda._sleep(1000)                         # the first call compiles / loads the spin kernel
+        torch.cuda.synchronize()
+        while len(kept) < count and len(kept) + len(rejected) < tries:
+            c = torch.cuda.Stream(device=device)
+            (kept if all(overlaps(c, k) for k in kept) else rejected).append(c)
+        while len(kept) < count:                        # no more luck: better a shared queue than no stream
+            kept.append(rejected.pop() if rejected else torch.cuda.Stream(device=device))
+    return kept
+
+
 class SelfPlayGroups:
     """The slots of a job as G independently ticking SelfPlay groups, each with its own engine, stream and tick graphs:
     the latency-bound search kernels of one group run beside the throughput-bound tower of another (C3, 1024 slots:
@@ -319,11 +357,14 @@ class SelfPlayGroups:
             streams = np.arange(self.n, dtype=np.uint32)
         streams = np.ascontiguousarray(streams, dtype=np.uint32)
         base, extra = int(episodes[0]), int(episodes[1])
+        import torch
+        hip_streams = concurrent_streams(torch, torch.device("cuda", kw.get("device", 0)), groups)
         self.parts = []
         for g in range(groups):
             lo = g * self.m
             part_extra = min(max(extra - lo, 0), self.m)           # slot s plays base + (s < extra) games, s global
-            self.parts.append(SelfPlay(config, network, self.m, streams=streams[lo:lo + self.m], episodes=(base, part_extra), **kw))
+            self.parts.append(SelfPlay(config, network, self.m, streams=streams[lo:lo + self.m], episodes=(base, part_extra),
+                                       hip_stream=hip_streams[g], **kw))
         p0 = self.parts[0]
         self.torch, self.device, self.net, self.config = p0.torch, p0.device, p0.net, config
         self.stream, self.grids, self.heads = p0.stream, p0.grids, p0.heads        # group 0's: what a probe of the tower looks at
@@ -370,14 +411,17 @@ class SelfPlayGroups:
 
 
 def slot_groups(config, network, n_slots):
-    """how many groups a job's slots are ticked in: TRL_SLOT_GROUPS, or 2 where it pays -- the all-native tick of a
-    16-filter AlphaSame (two tower workgroups per CU leave registers for the search kernel) with at least 512 slots;
-    the 64-filter tower owns its CU (138 KB of LDS, 500 registers per SIMD) and gains nothing"""
+    """how many groups a job's slots are ticked in: TRL_SLOT_GROUPS, or where it pays -- the all-native tick of a
+    16-filter AlphaSame (two tower workgroups per CU leave registers for the search kernel): 4 groups from 1024 slots
+    (C3: 0.160 ms per round of ticks against 0.177 with 2 and 0.20 with 1), 2 from 512; the 64-filter tower owns its CU
+    (138 KB of LDS, 500 registers per SIMD) and gains nothing"""
     env = os.environ.get("TRL_SLOT_GROUPS", "auto")
     if env != "auto":
         return max(1, int(env))
     mc = getattr(network, "model_config", None)
     native16 = type(network).__name__ == "AlphaSame" and getattr(mc, "filters", 0) == 16 and getattr(mc, "kernels", 1) == 1
+    if native16 and n_slots >= 1024 and n_slots % 4 == 0:
+        return 4
     return 2 if (native16 and n_slots >= 512 and n_slots % 2 == 0) else 1
 
 
