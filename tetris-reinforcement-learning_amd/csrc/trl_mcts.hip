@@ -127,7 +127,7 @@ struct ExpandShared {
     float  xs[HEAD_MAX_FEATS];
     float  zo[400];
     float  hv[20];
-    float  red_f[2];
+    float  red_f[4];
     double dsum;
     int    flag, chosen, rec_idx, end_idx;
 };
@@ -394,11 +394,14 @@ struct HeadsDev {
     int mask_want;                       // (two-network matches: one launch per network, gating.Battle)
 };
 
-template <int MODE>
+// NT = threads of the workgroup that take part (128, or 256 in the fused launch: the dense heads and the legal moves'
+// policy rows are independent dot products, twice the waves halve their dependent load steps)
+template <int MODE, int NT = BLOCK>
 static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMcts &M, trl_game_state *real, const float *values,
                                                    const float *policy, const float *head_w, const float *head_b, int feat_dim,
                                                    const HeadsDev &H) {
     constexpr bool HEAD = (MODE >= 1);
+    constexpr int NW = NT / 64, RPW = 16 / NW;       // waves; rows of a 16-row dense layer per wave
     const int tid = threadIdx.x, slot = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t nb = (size_t)slot * M.max_nodes;
     trl_game_state *pool = M.pool + (size_t)slot * M.cap_states;
@@ -418,33 +421,33 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
         const int q = pool[sh.ctl.leaf_state].turn, ps = sh.ctl.leaf_parent_state;
         float *zc = M.zcache + ((size_t)slot * M.cap_states) * 800;
         float *mine = zc + (size_t)sh.ctl.leaf_state * 800;
-        for (int i = tid; i < 400; i += BLOCK) {
+        for (int i = tid; i < 400; i += NT) {
             float a = (ps < 0) ? z[(size_t)slot * 400 + i] : zc[(size_t)ps * 800 + q * 400 + i];
             float o = z[((size_t)M.n_games + slot) * 400 + i];
             sh.xs[i] = a; sh.zo[i] = o;
             mine[q * 400 + i] = a; mine[(1 - q) * 400 + i] = o;
         }
-        for (int i = tid; i < TRL_VEC_FLOATS; i += BLOCK) sh.xs[i < 52 ? 400 + i : 416 + i] = vecp[i];
+        for (int i = tid; i < TRL_VEC_FLOATS; i += NT) sh.xs[i < 52 ? 400 + i : 416 + i] = vecp[i];
         __syncthreads();
         {                                                                     // opponent-side dense 400 -> 16, ReLU
             float zr[7];                                                      // all weight loads of a wave's 8 rows are issued
 #pragma unroll                                                                 // before the first use: one L2 round trip
             for (int t = 0; t < 7; t++) zr[t] = (lane + 64 * t < 400) ? sh.zo[lane + 64 * t] : 0.f;
-            float acc[8];
+            float acc[RPW];
 #pragma unroll
-            for (int jj = 0; jj < 8; jj++) {
-                const float *row = H.oside_w + (wave * 8 + jj) * 400;
+            for (int jj = 0; jj < RPW; jj++) {
+                const float *row = H.oside_w + (wave * RPW + jj) * 400;
                 float a = 0.f;
 #pragma unroll
                 for (int t = 0; t < 7; t++) a = fmaf((lane + 64 * t < 400) ? row[lane + 64 * t] : 0.f, zr[t], a);
                 acc[jj] = a;
             }
 #pragma unroll
-            for (int jj = 0; jj < 8; jj++) {
+            for (int jj = 0; jj < RPW; jj++) {
                 float a = acc[jj];
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
-                if (lane == 0) sh.xs[452 + wave * 8 + jj] = fmaxf(a + H.oside_b[wave * 8 + jj], 0.f);
+                if (lane == 0) sh.xs[452 + wave * RPW + jj] = fmaxf(a + H.oside_b[wave * RPW + jj], 0.f);
             }
         }
         __syncthreads();
@@ -452,21 +455,21 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
             float xr[9];
 #pragma unroll
             for (int t = 0; t < 9; t++) xr[t] = (lane + 64 * t < 521) ? sh.xs[lane + 64 * t] : 0.f;
-            float acc[8];
+            float acc[RPW];
 #pragma unroll
-            for (int jj = 0; jj < 8; jj++) {
-                const float *row = H.v0_w + (wave * 8 + jj) * 521;
+            for (int jj = 0; jj < RPW; jj++) {
+                const float *row = H.v0_w + (wave * RPW + jj) * 521;
                 float a = 0.f;
 #pragma unroll
                 for (int t = 0; t < 9; t++) a = fmaf((lane + 64 * t < 521) ? row[lane + 64 * t] : 0.f, xr[t], a);
                 acc[jj] = a;
             }
 #pragma unroll
-            for (int jj = 0; jj < 8; jj++) {
+            for (int jj = 0; jj < RPW; jj++) {
                 float a = acc[jj];
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
-                if (lane == 0) sh.hv[wave * 8 + jj] = fmaxf(a + H.v0_b[wave * 8 + jj], 0.f);
+                if (lane == 0) sh.hv[wave * RPW + jj] = fmaxf(a + H.v0_b[wave * RPW + jj], 0.f);
             }
         }
         __syncthreads();
@@ -490,7 +493,7 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
         if (HEAD) {
             if (MODE == 1) {
                 const float *xf = policy + (size_t)slot * feat_dim;
-                for (int i = tid; i < feat_dim; i += BLOCK) sh.xs[i] = xf[i];  // the leaf's feature vector, staged once
+                for (int i = tid; i < feat_dim; i += NT) sh.xs[i] = xf[i];  // the leaf's feature vector, staged once
                 __syncthreads();
             }
             float lmax = -INFINITY;
@@ -498,7 +501,7 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
                 float xr[9];
 #pragma unroll
                 for (int t = 0; t < 9; t++) xr[t] = (lane + 64 * t < 521) ? sh.xs[lane + 64 * t] : 0.f;
-                for (int k0 = wave * 4; k0 < n; k0 += (BLOCK / 64) * 4) {          // 4 moves per wave and step: 36 loads in flight
+                for (int k0 = wave * 4; k0 < n; k0 += NW * 4) {          // 4 moves per wave and step: 36 loads in flight
                     float acc[4]; int idx[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
@@ -527,7 +530,7 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
                 // any feature width (the BaseResNet family: 1 657): four moves per wave and step share every read of the
                 // staged feature vector and keep four times the weight-row loads in flight (one move per step before:
                 // k_expand<1> 104 us per tick of 1024 slots)
-                for (int k0 = wave * 4; k0 < n; k0 += (BLOCK / 64) * 4) {
+                for (int k0 = wave * 4; k0 < n; k0 += NW * 4) {
                     const float *row[4]; int idx[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
@@ -554,7 +557,12 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
             }
             if (lane == 0) sh.red_f[wave] = lmax;
             __syncthreads();
-            lmax = fmaxf(sh.red_f[0], sh.red_f[1]);
+            lmax = sh.red_f[0];
+#pragma unroll
+            for (int w = 1; w < NW; w++) lmax = fmaxf(lmax, sh.red_f[w]);
+            // the independent dot products are done: waves beyond the first two end here (a wave that has ended no longer
+            // counts at the workgroup's barriers), everything below is a dependent chain that more threads only lengthen
+            if (NT > BLOCK && tid >= BLOCK) return;
             __syncthreads();
             for (int k = tid; k < n; k += BLOCK) {
                 float p = expf(sh.pf[k] - lmax);
@@ -579,7 +587,10 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
             for (int d = 32; d >= 1; d >>= 1) mymax = fmaxf(mymax, __shfl_down(mymax, d, 64));
             if (lane == 0) sh.red_f[wave] = mymax;
             __syncthreads();
-            const double log_max = log((double)fmaxf(sh.red_f[0], sh.red_f[1]));
+            float rmax = sh.red_f[0];
+#pragma unroll
+            for (int w = 1; w < NW; w++) rmax = fmaxf(rmax, sh.red_f[w]);
+            const double log_max = log((double)rmax);
             const double inv_temp = 1.0 / cfg.root_softmax_temp;
             for (int k = tid; k < n; k += BLOCK) sh.pd[k] = exp((log((double)sh.pf[k]) - log_max) * inv_temp);
         }
@@ -609,6 +620,7 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
         __syncthreads();
     }
 
+    if (NT > BLOCK && tid >= BLOCK) return;
     // NOISE (ai.py:482-499): un-normalised gamma draws on the root's children
     MPROF_T(me2); MPROF_ADD(9, me1, me2);
     if (cfg.training && !sh.ctl.fast && cfg.use_dirichlet && leaf == 0 && !sh.ctl.random_move) {
@@ -840,14 +852,16 @@ constexpr int SEARCH_PRIO = TRL_SEARCH_PRIO;
 // the launch ends with the slowest expand + select of one slot, not with the slowest expand plus the slowest select.
 // `vec` is read by the expand (the leaf's feature vector) before the same workgroup's select overwrites it; `grids` were
 // consumed by the tower that ran before this launch.
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_expand_select(DevMcts M, trl_game_state *real, float *vec, const float *z,
+constexpr int FUSED_THREADS = 256;        // four waves for the expand half, the first two go on to the selection
+__global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_expand_select(DevMcts M, trl_game_state *real, float *vec, const float *z,
                                                          const float *head_w, const float *head_b, HeadsDev H, float *grids,
                                                          uint8_t *need) {
     __shared__ union U { ExpandShared e; SelectShared s; __device__ U() {} } sh;
     // latency-bound (two waves per slot, long dependent chains): when the other slot group's tower shares the SIMD, these
     // waves go first -- they issue rarely, so the tower loses little and the search chain of the tick gets shorter
     __builtin_amdgcn_s_setprio(SEARCH_PRIO);
-    expand_body<2>(sh.e, M, real, vec, z, head_w, head_b, 521, H);
+    expand_body<2, FUSED_THREADS>(sh.e, M, real, vec, z, head_w, head_b, 521, H);
+    if (threadIdx.x >= BLOCK) return;              // (slots that were not expanding: the extra waves end here)
     __syncthreads();                               // the tree and the slot's control block are in memory; the LDS block changes hands
     select_body(sh.s, M, real, grids, vec, need, 1);
 }
@@ -1160,7 +1174,7 @@ int trl_mcts_expand_alphasame_select(trl_engine *h, const float *dev_z, float *d
     if (h->mcts->d.cfg.move_algorithm != TRL_ALGO_CONVOLUTIONAL)
         return fail(TRL_E_STATE, "%s", "trl_mcts_expand_alphasame_select: the fused launch runs the 'convolutional' generator only");
     HeadsDev H{w->oside_w, w->oside_b, w->value0_w, w->value0_b, w->value3_w, w->value3_b, w->use_tanh, nullptr, 0};
-    hipLaunchKernelGGL(k_expand_select, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_vec,
+    hipLaunchKernelGGL(k_expand_select, dim3(h->cfg.n_games), dim3(FUSED_THREADS), 0, h->stream, h->mcts->d, h->d_states, dev_vec,
                        dev_z, w->policy_w, w->policy_b, H, dev_grids, dev_need);
     HIPCHK(hipGetLastError());
     h->mcts->ticks++;

@@ -1170,7 +1170,9 @@ int trl_alphasame_trunk16_split(const float *dev_boards, int n_boards, const flo
     // conv_step); TRL_SPLIT_ILV = 0 / 1 forces one form (probe knob).  Three boards per CU (168 registers, measured with
     // the same kernel) ran at the speed of two: 768 boards 89 against 96 us, 1536 169 against 172.
     static const int force = getenv("TRL_SPLIT_ILV") ? atoi(getenv("TRL_SPLIT_ILV")) : -1;
-    if (force < 0 ? n_boards <= 256 : force != 0)
+    // (with need flags about half of the boards are skipped at once: the tick of a 512-slot group has ~512 live boards of
+    // 1024, and there the interleaved form was 1.5 % faster as well, beside the other groups' kernels)
+    if (force < 0 ? n_boards <= (dev_need ? 1024 : 256) : force != 0)
         hipLaunchKernelGGL((k_trunk16s<2, true>), dim3(n_boards), dim3(TRUNK_THREADS), 0, (hipStream_t)stream, dev_boards,
                            dev_packed, n_blocks, dev_out, dev_need);
     else
