@@ -107,12 +107,19 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
     t0 = time.perf_counter()
     done = 0
     drained = []
-    while done < args.mcts_ticks:
-        k = min(512, args.mcts_ticks - done)
-        sp.tick(k)
-        done += k
-        drained.append(sp.drain_dev())                 # records leave the search's buffer inside the timed region, stay in HBM
+    k = min(512, args.mcts_ticks)
+    sp.tick(k)
+    done = k
+    while True:
+        nxt = min(512, args.mcts_ticks - done)
+        # records leave the search's buffer inside the timed region and stay in HBM; a slot group that has handed its
+        # records over goes on with the next chunk of ticks while the next group is drained
+        drained.append(sp.drain_dev(then_tick=nxt))
+        done += nxt
+        if nxt == 0:
+            break
     sp.synchronize()
+    t_ticks = time.perf_counter() - t0
     # C4: the one exchange step of the path -- every rank's packed (state, pi, z) move records to rank 0: over RCCL
     # GPU -> GPU (dist.gather, no host bounce on the senders), then one copy to rank 0's host
     with torch.cuda.stream(sp.stream):
@@ -128,6 +135,9 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
         gathered = int(mine.cpu().numel())
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("TRL_BENCH_DEBUG"):
+        sys.stderr.write("[bench] C3 timed region %.1f ms: ticks + drains %.1f ms, gather + host copy %.1f ms\n"
+                         % (elapsed * 1e3, t_ticks * 1e3, (elapsed - t_ticks) * 1e3))
     st1 = sp.stats()
     if st1["overflow"] or st1["records_dropped"] or st1.get("tower_overflow"):
         raise SystemExit("tree / record capacity (or the split towers' activation range) overflowed during the MCTS benchmark: results invalid")
@@ -254,6 +264,9 @@ def bench_c5(args, rank, local_rank, world, dist, dev, barrier):
     sp.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("TRL_BENCH_DEBUG"):
+        sys.stderr.write("[bench] C3 timed region %.1f ms: ticks + drains %.1f ms, gather + host copy %.1f ms\n"
+                         % (elapsed * 1e3, t_ticks * 1e3, (elapsed - t_ticks) * 1e3))
     st1 = sp.stats()
     if st1["overflow"] or st1["records_dropped"] or st1.get("tower_overflow"):
         raise SystemExit("tree / record capacity (or the split towers' activation range) overflowed during the C5 benchmark: results invalid")
@@ -347,7 +360,7 @@ def cpu_baseline_mcts(seconds_target=12.0, blocks=10, filters=16, max_iter=160, 
                       % (blocks, filters, moves, sims, dt)}
 
 
-def load_pmc(name="r02_env_rollout_pmc.json"):
+def load_pmc(name="r03_env_rollout_pmc.json"):
     """per-ply figures of k_rollout from the committed rocprofv3 --pmc passes (profiles/): HBM-side bytes per ply and
     game, vector-ALU instructions per wave and ply -- measured at the launch lengths listed in the file"""
     try:

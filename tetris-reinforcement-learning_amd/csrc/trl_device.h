@@ -403,6 +403,7 @@ struct alignas(8) CsScratch {
     uint64_t fcol[20];               // free cells of board column x (bit = map row) at index x + 2, zero elsewhere
     uint64_t vcol[4 * 20];           // valid[rot] column mx at index rot * 20 + mx + 2; the other entries are zero guards
     uint64_t arr[2][4 * 20];         // kick arrivals, same indexing: [1] through the last kick of a list (T, not 180), [0] others
+    uint64_t kick[12];               // this piece's kick lists, [rot * 3 + dir - 1] (six registers less across the fixed point)
 };
 static_assert(sizeof(CsScratch) <= sizeof(MgScratch), "the closure search's scratch shares the ordered walk's memory");
 
@@ -431,8 +432,9 @@ __device__ __forceinline__ void scatter_column(uint16_t *plane, uint64_t col, in
     }
 }
 
+// returns the number of placements, or -1: a T search whose sub-planes depend on the walk's order (take the ordered walk)
 static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows, int type, bool need_spawn, CsScratch &C,
-                                                           uint16_t *out, int out_cap, int lane, int *overflow, bool *need_ordered) {
+                                                           uint16_t *out, int out_cap, int lane, int *overflow) {
     const int rot = lane >> 4, mx = lane & 15;
     const bool isT = (type == PT), check_rot = (type != PO);
     // free cells per board column: ten ballots over the rows (lane = board row), column x kept by lane x + 2
@@ -445,6 +447,7 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
         if (lane == x + 2) mine = fr;
     }
     if (lane < 20) C.fcol[lane] = mine;
+    if (lane < 12) C.kick[lane] = C_KICK[((type == PI) ? 12 : 0) + lane];
     {
         uint32_t *z = reinterpret_cast<uint32_t *>(&C.arr[0][0]);
         for (int i = lane; i < 2 * 4 * 20 * 2; i += 64) z[i] = 0;
@@ -475,15 +478,10 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
     const uint64_t v0 = C.vcol[sx + 2 + 2];                 // rotation 0, column sx + 2
     bool ok = (v0 >> (sy + 2)) & 1;                                                      // :349-351
     if (need_spawn) ok = ok && ((v0 >> (SPAWN_Y + 2)) & 1);                              // player.py:40
-    *need_ordered = false;
     if (!uni(ok)) return 0;
 
     // edge cells (:427-431): cannot move down, or a side neighbour is not valid.  (valid >> 1: bit my = the cell below is valid)
     const uint64_t edge = valid & (~(valid >> 1) | ~dpp64(valid, 0) | ~dpp64(valid, 1));
-    const int ktab = (type == PI) ? 12 : 0;
-    uint64_t kt[3];
-#pragma unroll
-    for (int d = 0; d < 3; d++) kt[d] = check_rot ? C_KICK[ktab + rot * 3 + d] : 0ull;
     uint64_t reach = (lane == sx + 2) ? (1ull << (sy + 2)) : 0ull;
     uint64_t done = 0;
     for (;;) {
@@ -502,9 +500,9 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             const int nrot = (rot + d + 1) & 3;
-            const int nk = (int)(kt[d] >> 60);
+            uint64_t kq = C.kick[rot * 3 + d];
+            const int nk = (int)(kq >> 60);
             uint64_t rem = src;
-            uint64_t kq = kt[d];
 #pragma unroll 1
             for (int ki = 0; ki < 6; ki++, kq >>= 6) {
                 if (!__ballot(rem != 0 && ki < nk)) break;
@@ -531,7 +529,7 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
     const uint64_t stuck = valid & ~(valid >> 1);
     if (isT) {
         const uint64_t f1 = C.arr[1][rot * 20 + mx + 2] & stuck, f0 = C.arr[0][rot * 20 + mx + 2] & stuck;
-        if (__ballot((f1 & f0) != 0)) { *need_ordered = true; return 0; }               // the walk's order decides: take it
+        if (__ballot((f1 & f0) != 0)) return -1;                                        // the walk's order decides: take it
         scatter_column(&C.flagp[0][0], f1 | f0, rot, mx);
         scatter_column(&C.ulp[0][0], f1, rot, mx);
     }
@@ -549,9 +547,8 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
 static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int type, bool need_spawn, MgScratch &S,
                                                    uint16_t *out, int out_cap, int lane, int *overflow) {
 #if TRL_CLOSURE
-    bool ordered = false;
-    const int n = movegen_closure_wave(rows, type, need_spawn, reinterpret_cast<CsScratch &>(S), out, out_cap, lane, overflow, &ordered);
-    if (!ordered) return n;
+    const int n = movegen_closure_wave(rows, type, need_spawn, reinterpret_cast<CsScratch &>(S), out, out_cap, lane, overflow);
+    if (n >= 0) return n;
 #endif
     return movegen_ordered_wave(rows, type, need_spawn, S, out, out_cap, lane, overflow);
 }

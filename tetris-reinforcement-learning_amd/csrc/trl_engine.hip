@@ -138,7 +138,13 @@ __global__ __launch_bounds__(BLOCK, 8) void k_rollout(trl_game_state *states, ui
             else if (rank < ((rankt >> 16) & 255)) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
         }
-        int total = block_movegen(sh, tid);
+        // the thread index through an opaque move, once per ply: everything the search derives from it (lane, rotation, map
+        // column, LDS addresses, a dozen lane predicates) is then recomputed per ply instead of being hoisted out of the ply
+        // loop and kept in registers for the whole launch -- at 64 registers per lane that hoisting cost 9 spilled registers
+        // (19 MB of scratch written per launch, more than the game states themselves)
+        int tid_p = tid;
+        asm volatile("" : "+v"(tid_p));
+        int total = block_movegen(sh, tid_p);
         if (tid < 64) {
             trl_game_state &g = sh.g;
             if (tid == 0 && sh.overflow) g.flags |= TRL_FLAG_OVERFLOW;
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(BLOCK, 8) void k_rollout(trl_game_state *states, ui
                 int idx = (int)rng_below(seed, g.stream, TRL_RNG_POLICY, g.pol_ctr, (uint32_t)total);
                 wave_sync();
                 if (tid == 0) g.pol_ctr++;
-                make_move(g, seed, merged_move(sh, idx), true, tid);
+                make_move(g, seed, merged_move(sh, idx), true, tid_p);
                 steps++;
             }
             if (tid == 0 && (total == 0 || is_terminal(g) || (int)g.ply >= max_plies)) {

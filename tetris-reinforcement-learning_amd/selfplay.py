@@ -279,8 +279,9 @@ class SelfPlay:
         self.stream.synchronize()
         return self.engine.mcts_drain_records()
 
-    def drain_dev(self):
-        """pending records as a uint8 tensor in HBM (n * 2392 bytes): the payload of the RCCL gather to rank 0"""
+    def drain_dev(self, then_tick=0):
+        """pending records as a uint8 tensor in HBM (n * 2392 bytes): the payload of the RCCL gather to rank 0.
+        then_tick: ticks to enqueue right after the copy, before this call waits for it -- the device goes on searching"""
         torch = self.torch
         cap = self.engine._rec_cap
         with torch.cuda.stream(self.stream):
@@ -288,8 +289,12 @@ class SelfPlay:
                 self._rec_dev = torch.empty(cap * _eng.RECORD_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
             n = self.engine.mcts_drain_records_dev(self._rec_dev.data_ptr(), cap)
             out = self._rec_dev[:n * _eng.RECORD_DTYPE.itemsize].clone()
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        if then_tick > 0:
+            self.tick(then_tick)
         # the clone was enqueued on this object's stream; its readers (torch.cat, the RCCL gather) run on theirs
-        self.stream.synchronize()
+        done.synchronize()
         return out
 
     def stats(self):
@@ -389,18 +394,19 @@ class SelfPlayGroups:
                 out.append(r)
         return np.concatenate(out) if out else np.zeros(0, dtype=_eng.RECORD_DTYPE)
 
-    def drain_dev(self):
+    def drain_dev(self, then_tick=0):
+        """group by group: a group that has handed over its records goes on ticking (then_tick) while the next is drained"""
         torch, size = self.torch, _eng.RECORD_DTYPE.itemsize
         out = []
         for g, p in enumerate(self.parts):
-            t = p.drain_dev()
+            t = p.drain_dev(then_tick)
             if t.numel() and g:
-                with torch.cuda.stream(p.stream):
-                    t.view(-1, size)[:, :4].view(torch.int32).add_(g * self.m)        # the record's slot field (first word)
-            p.stream.synchronize()
+                t.view(-1, size)[:, :4].view(torch.int32).add_(g * self.m)            # the record's slot field (first word)
             out.append(t)
-        with torch.cuda.stream(self.stream):
-            return torch.cat(out) if len(out) > 1 else out[0]
+        self.ticks += then_tick
+        res = torch.cat(out) if len(out) > 1 else out[0]                              # (current stream: the copies are complete)
+        torch.cuda.current_stream(self.device).synchronize()
+        return res
 
     def stats(self):
         sts = [p.stats() for p in self.parts]
