@@ -385,12 +385,6 @@ int  trl_alphasame_trunk16_need(const float *dev_boards, int n_boards, const flo
  * (nets.AlphaSame._pack_tower_split).  dev_need may be NULL.                                                         */
 int  trl_alphasame_trunk16_split(const float *dev_boards, int n_boards, const float *dev_packed, int n_blocks,
                                  float *dev_out, const uint8_t *dev_need, void *stream);
-/* The same, a conv walked tile outermost with its whole weights in registers and the split-and-write of a pair of tiles under
- * the next pair's matrix instructions (csrc/trl_net.hip k_trunk16p; two sets of activation planes, 73 KB of LDS per board).
- * dev_packed as above with every 3x3 conv as [5 K-steps][2^11 hi | hi | lo][64 lanes][8 halves] and >= 16 KiB of padding
- * (nets.AlphaSame._pack_tower_split(pipe=True)).                                                                            */
-int  trl_alphasame_trunk16_pipe(const float *dev_boards, int n_boards, const float *dev_packed, int n_blocks,
-                                float *dev_out, const uint8_t *dev_need, void *stream);
 /* The 32- and 64-filter towers in the same way (csrc/trl_net.hip k_trunk_wide_s): resnet = 0: AlphaSame, contract of
  * trl_alphasame_trunk (kout ignored); resnet != 0: the BaseResNet family, contract of trl_resnet_trunk.  dev_packed as for
  * those, with every 3x3 conv as [K-step = kg * 9 + tap][hi | lo][N-tile][64 lanes][8 halves] (nets._pack_conv3x3_split_wide). */

@@ -573,231 +573,6 @@ __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *_
 }
 
 
-// ---- k_trunk16p: the split 16-filter tower with the split-and-write phase under the matrix instructions (round 3) -------
-// k_trunk16s walks a conv K-step outermost: the accumulators of all of a wave's tiles complete together at the end, and the
-// wave then splits and writes them while its matrix pipe idles (2 250 of a block's 8 000 cycles), behind a barrier that has
-// to wait until every wave has read its halo out of the single set of planes (in-kernel stamps, r02u_tower16s_phase.txt).
-// Here a conv is walked TILE outermost, two tiles at a time, with the conv's whole weights in registers (5 K-steps x
-// {2^11 hi, hi, lo} x 4 registers = 60; the scaled hi half comes packed from the host, nets._pack_conv3x3_split3): a pair's
-// accumulators are final after its 30 matrix instructions, and its split-and-write runs in the shadow of the NEXT pair's.
-// That needs a second set of planes -- conv A reads set 0 and writes set 1, conv B reads set 1 and writes set 0 (73 KB of
-// LDS per board, still two boards per CU) -- and leaves two barriers per block instead of four.  The next conv's weights
-// replace the current ones K-step by K-step during the wave's last pair, as each step's registers fall dead.
-// Tile 24 (25 tiles over 4 waves) is no longer K-split: the wave `block & 3` takes it whole, before its pairs, and keeps
-// the tile's residual stream in LDS for the next owner (1 KB) -- no partial sums, no extra barrier; a conv is as long as its
-// seven-tile wave (1 680 cycles of matrix instructions against 1 500 balanced).
-constexpr int WCONV_P = 5 * 3 * 64 * 4;          // packed dwords per 3x3 conv: [K-step][2^11 hi | hi | lo][lane][8 halves]
-constexpr int WBLOCK_P = 16 + 16 + WCONV_P + 16 + WCONV_P;
-constexpr int PLANE_H = HPLANE * 2;              // halves per set of planes
-
-struct ConvW { f16x8 s[5], h[5], l[5]; };           // a conv's weights: 2^11 hi, hi, lo per K-step
-
-template <int C> __device__ __forceinline__ const _Float16 *pb_ptr(const _Float16 *base, int d1, int d10) {
-    constexpr int A[5] = {0, 2, SPW + 1, 2 * SPW, 2 * SPW + 2};
-    return (C == 1 ? base + d10 : (C == 4 ? base : base + d1)) + A[C] * HST;
-}
-struct Frag { f16x8 h, l; };
-template <int C> __device__ __forceinline__ Frag pb_load(const _Float16 *base, int d1, int d10) {
-    const _Float16 *p = pb_ptr<C>(base, d1, d10);
-    Frag f;
-    f.h = *reinterpret_cast<const f16x8 *>(p);
-    f.l = *reinterpret_cast<const f16x8 *>(p + LO_OFS);
-    return f;
-}
-template <int C> __device__ __forceinline__ void pw_load(ConvW &w, const uint4 *wp) {
-    w.s[C] = __builtin_bit_cast(f16x8, wp[(3 * C) * 64]);
-    w.h[C] = __builtin_bit_cast(f16x8, wp[(3 * C + 1) * 64]);
-    w.l[C] = __builtin_bit_cast(f16x8, wp[(3 * C + 2) * 64]);
-}
-// (a single tile's K-step: tile 24, by the block's owner)
-template <int C>
-__device__ __forceinline__ void pstep1(const ConvW &w, const _Float16 *b0, int d1, int d10, Frag &f0, f32x4 &a0) {
-    __builtin_amdgcn_sched_barrier(0);
-    Frag n0 = f0;
-    if constexpr (C + 1 < 5) n0 = pb_load<C + 1>(b0, d1, d10);
-    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.s[C], f0.h, a0, 0, 0, 0);
-    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[C], f0.l, a0, 0, 0, 0);
-    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.l[C], f0.h, a0, 0, 0, 0);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    f0 = n0;
-}
-
-// unit U of a conv's three pairs of tiles: one scheduling region with the requests for unit U + 2's fragments, the six matrix
-// instructions of (pair U / 5, K-step U % 5), a finished tile's epilogue where one is due, and -- during the last pair -- the
-// refill of the step's weight registers with the next conv's
-template <int U, class FIN>
-__device__ __forceinline__ void unit16p(ConvW &w, const uint4 *wnext, const _Float16 *src, const int (&off)[7], int d1, int d10,
-                                        Frag (&fr)[3][2], f32x4 (&acc)[3][2], FIN &finish, f32x4 (&x)[7]) {
-    constexpr int PAIR = U / 5, C = U % 5, CUR = U % 3, NXT = (U + 2) % 3;
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (U + 2 < 15) {
-        constexpr int P2 = (U + 2) / 5, C2 = (U + 2) % 5;
-        fr[NXT][0] = pb_load<C2>(src + off[2 * P2], d1, d10);
-        fr[NXT][1] = pb_load<C2>(src + off[2 * P2 + 1], d1, d10);
-    }
-    f32x4 &a0 = acc[PAIR][0], &a1 = acc[PAIR][1];
-    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.s[C], fr[CUR][0].h, a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.s[C], fr[CUR][1].h, a1, 0, 0, 0);
-    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[C], fr[CUR][0].l, a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.h[C], fr[CUR][1].l, a1, 0, 0, 0);
-    a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.l[C], fr[CUR][0].h, a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w.l[C], fr[CUR][1].h, a1, 0, 0, 0);
-    // epilogues of the pair before: its first tile under this pair's K-step 0, its second under K-step 2
-    if constexpr (PAIR >= 1 && C == 0) finish(2 * (PAIR - 1), acc[PAIR - 1][0], x[2 * (PAIR - 1)]);
-    if constexpr (PAIR >= 1 && C == 2) finish(2 * (PAIR - 1) + 1, acc[PAIR - 1][1], x[2 * (PAIR - 1) + 1]);
-    if constexpr (PAIR == 2) pw_load<C>(w, wnext);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-    __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (U + 1 < 15) unit16p<U + 1>(w, wnext, src, off, d1, d10, fr, acc, finish, x);
-}
-
-// One conv of the wave.  IS_B = false: conv A -- out = relu(conv + bias), split, written to `dst`.  IS_B = true: conv B --
-// x += conv; out = relu(x * sc + sh) (the next block's first batch norm), split, written to `dst` unless `last`.
-// off[s]: the lane's offset (halves) of tile s's 3x3 window in a set of planes; wnext: the next conv's packed weights.
-template <bool IS_B>
-__device__ __forceinline__ void conv16p(const _Float16 *src, _Float16 *dst, const int (&off)[7], int d1, int d10, int wofs,
-                                        ConvW &w, const uint4 *wnext, bool owner, bool last, f32x4 bias, f32x4 sc, f32x4 sh,
-                                        f32x4 (&x)[7], float *x24, int lane, float &act_max) {
-    auto finish = [&](int s, f32x4 a, f32x4 &xs) {          // the epilogue of one tile
-        f32x4 v = a * INV_SPLIT;
-        if (IS_B) { xs += v; v = __builtin_elementwise_fma(xs, sc, sh); }
-        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-        if (!IS_B || !last) store_split4(dst + off[s], dst + off[s] + LO_OFS, wofs, v, act_max);
-    };
-    const f32x4 init = IS_B ? f32x4{0.f, 0.f, 0.f, 0.f} : bias * SPLIT;
-    if (owner) {                                             // tile 24, whole, by this block's owner
-        f32x4 a = init;
-        Frag f = pb_load<0>(src + off[6], d1, d10);
-        pstep1<0>(w, src + off[6], d1, d10, f, a); pstep1<1>(w, src + off[6], d1, d10, f, a);
-        pstep1<2>(w, src + off[6], d1, d10, f, a); pstep1<3>(w, src + off[6], d1, d10, f, a);
-        pstep1<4>(w, src + off[6], d1, d10, f, a);
-        if (IS_B) {
-            f32x4 x6 = *reinterpret_cast<const f32x4 *>(x24 + lane * 4);
-            finish(6, a, x6);
-            *reinterpret_cast<f32x4 *>(x24 + lane * 4) = x6;
-        } else finish(6, a, x[6]);
-    }
-    // the three pairs as 15 units (pair = U / 5, K-step = U % 5); the fragments of unit U + 2 are requested in unit U (one
-    // unit of matrix instructions is 96 cycles, an LDS round trip of four 16-byte reads per lane beside three other waves'
-    // about twice that: a distance of one left the wave waiting at every step)
-    f32x4 acc[3][2] = {{init, init}, {init, init}, {init, init}};
-    Frag fr[3][2];
-    auto base = [&](int pair, int t) { return src + off[2 * pair + t]; };
-    fr[0][0] = pb_load<0>(base(0, 0), d1, d10); fr[0][1] = pb_load<0>(base(0, 1), d1, d10);
-    fr[1][0] = pb_load<1>(base(0, 0), d1, d10); fr[1][1] = pb_load<1>(base(0, 1), d1, d10);
-    unit16p<0>(w, wnext, src, off, d1, d10, fr, acc, finish, x);
-    finish(4, acc[2][0], x[4]);
-    finish(5, acc[2][1], x[5]);
-}
-
-__global__ __launch_bounds__(TRUNK_THREADS, 2) void k_trunk16p(const float *__restrict__ boards, const float *__restrict__ wts,
-                                                               int n_blocks, float *__restrict__ out,
-                                                               const uint8_t *__restrict__ need) {
-    if (need && !need[blockIdx.x]) return;
-    __builtin_amdgcn_s_setprio(3);
-    __shared__ __attribute__((aligned(16))) float lds[2 * HPLANE + BW * BH + 256];
-    _Float16 *P0 = reinterpret_cast<_Float16 *>(lds), *P1 = P0 + PLANE_H;
-    float *brd = lds + 2 * HPLANE, *x24 = lds + 2 * HPLANE + BW * BH;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, pn = lane & 15;      // result layout: channels 4 g + r of tile position pn
-    const size_t board = blockIdx.x;
-
-    for (int i = tid; i < (2 * HPLANE + BW * BH + 256) / 4; i += TRUNK_THREADS)
-        reinterpret_cast<f32x4 *>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-    for (int i = tid; i < 400; i += TRUNK_THREADS) brd[(i / 10 + 2) * BW + (i % 10) + 2] = boards[board * 400 + i];
-    __syncthreads();
-
-    int off[7];                     // the lane's position in tile s: offset of its 3x3 window in a set of planes (as SBase::p0)
-#pragma unroll
-    for (int s = 0; s < 7; s++) {
-        const int T = (s < 6) ? wave + 4 * s : NT - 1;
-        const int p = 16 * T + pn;
-        off[s] = ((p / 10) * SPW + (p % 10)) * HST + 8 * (g & 1);
-    }
-    const int d1 = (g >> 1) * HST, d10 = (g >> 1) * (SPW - 2) * HST;
-    const int WOFS = (SPW + 1) * HST + 4 * g - 8 * (g & 1);
-    // 5x5 stem on the fp32 matrix instruction, as in k_trunk16s
-    f32x4 x[7];
-    {
-        float wB[7];
-        int toff[7];
-#pragma unroll
-        for (int st = 0; st < 7; st++) {
-            const int t = 4 * st + g, tc = t < 25 ? t : 24;
-            wB[st] = t < 25 ? wts[pn * 25 + tc] : 0.f;
-            toff[st] = (tc / 5) * BW + (tc % 5);
-        }
-#pragma unroll
-        for (int s = 0; s < 7; s++) {
-            int T = wave + 4 * s; if (T >= NT) T = NT - 1;
-            const int p = 16 * T + pn, pb = (p / 10) * BW + (p % 10);
-            f32x4 c = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int st = 0; st < 7; st++) c = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[st], brd[pb + toff[st]], c, 0, 0, 0);
-            x[s] = c;
-        }
-    }
-    float act_max = 0.f;
-    const float *wb = wts + 400;
-    ConvW w;
-    {
-        const uint4 *wpa = reinterpret_cast<const uint4 *>(wb + 32) + lane;
-        pw_load<0>(w, wpa); pw_load<1>(w, wpa); pw_load<2>(w, wpa); pw_load<3>(w, wpa); pw_load<4>(w, wpa);
-        // the first block's conv input: relu(bn1(x)), split, into set 0 (every wave its tiles, wave 0 tile 24 and its stream)
-        const f32x4 s1 = *reinterpret_cast<const f32x4 *>(wb + 4 * g), t1 = *reinterpret_cast<const f32x4 *>(wb + 16 + 4 * g);
-#pragma unroll
-        for (int s = 0; s < 7; s++) {
-            if (s < 6 || wave == 0) {
-                f32x4 v = __builtin_elementwise_fma(x[s], s1, t1);
-                v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-                store_split4(P0 + off[s], P0 + off[s] + LO_OFS, WOFS, v, act_max);
-            }
-        }
-        if (wave == 0) *reinterpret_cast<f32x4 *>(x24 + lane * 4) = x[6];
-    }
-    __syncthreads();
-    for (int b = 0; b < n_blocks; b++, wb += WBLOCK_P) {
-        const bool owner = wave == (b & 3), last = b + 1 == n_blocks;
-        const f32x4 bias_a = *reinterpret_cast<const f32x4 *>(wb + 32 + WCONV_P + 4 * g);
-        const uint4 *wpb = reinterpret_cast<const uint4 *>(wb + 32 + WCONV_P + 16) + lane;
-        const uint4 *wpa_next = reinterpret_cast<const uint4 *>(wb + WBLOCK_P + 32) + lane;     // (past the last block: the tail + padding, unused)
-        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
-        if (!last) { sc = *reinterpret_cast<const f32x4 *>(wb + WBLOCK_P + 4 * g); sh = *reinterpret_cast<const f32x4 *>(wb + WBLOCK_P + 16 + 4 * g); }
-        __builtin_amdgcn_s_setprio(0);
-        conv16p<false>(P0, P1, off, d1, d10, WOFS, w, wpb, owner, false, bias_a, sc, sh, x, x24, lane, act_max);
-        __syncthreads();
-        conv16p<true>(P1, P0, off, d1, d10, WOFS, w, wpa_next, owner, last, bias_a, sc, sh, x, x24, lane, act_max);
-        __builtin_amdgcn_s_setprio(3);
-        __syncthreads();
-    }
-    report_split_range(act_max);
-    if (wave == 0) x[6] = *reinterpret_cast<const f32x4 *>(x24 + lane * 4);
-    // tail: relu(bn(x)) -> 1x1 conv over the 16 channels (4 in the lane, 4 lane groups) -> folded bn -> relu   (fp32)
-    const f32x4 s = *reinterpret_cast<const f32x4 *>(wb + 4 * g), t = *reinterpret_cast<const f32x4 *>(wb + 16 + 4 * g);
-    const f32x4 wk = *reinterpret_cast<const f32x4 *>(wb + 32 + 4 * g);
-    const float bk = wb[48];
-#pragma unroll
-    for (int sidx = 0; sidx < 7; sidx++) {
-        const int T = wave + 4 * sidx;
-        f32x4 y = x[sidx] * s + t;
-        float v = fmaxf(y[0], 0.f) * wk[0];
-        v = fmaf(fmaxf(y[1], 0.f), wk[1], v); v = fmaf(fmaxf(y[2], 0.f), wk[2], v); v = fmaf(fmaxf(y[3], 0.f), wk[3], v);
-        v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
-        if (g == 0 && T < NT) out[board * 400 + 16 * T + pn] = fmaxf(v + bk, 0.f);
-    }
-}
-
-
 // ---- wide tower: 32 / 64 filters (BASELINE config C5: 20 blocks x 64 filters) ------------------------------------
 // Same algorithm and data layout as k_trunk16, generalised over the channel count FF (a multiple of 16):
 //   * the activations are FF/4 quad-planes of [42 x 12 padded positions][4 channels] in LDS (FF = 64: 126 KB, one
@@ -1403,19 +1178,6 @@ int trl_alphasame_trunk16_split(const float *dev_boards, int n_boards, const flo
     else
         hipLaunchKernelGGL((k_trunk16s<2, false>), dim3(n_boards), dim3(TRUNK_THREADS), 0, (hipStream_t)stream, dev_boards,
                            dev_packed, n_blocks, dev_out, dev_need);
-    HIPCHK(hipGetLastError());
-    return TRL_OK;
-}
-
-// The same tower, walked tile outermost with the split-and-write under the next tiles' matrix instructions (k_trunk16p);
-// dev_packed in the layout of nets.AlphaSame._pack_tower_split3(): as for trl_alphasame_trunk16_split, with every 3x3 conv
-// as [K-step][2^11 hi | hi | lo][lane][8 halves] and 16 KiB of padding at the end.  Same contract otherwise.
-int trl_alphasame_trunk16_pipe(const float *dev_boards, int n_boards, const float *dev_packed, int n_blocks,
-                               float *dev_out, const uint8_t *dev_need, void *stream) {
-    if (!dev_boards || !dev_packed || !dev_out || n_boards <= 0 || n_blocks < 0)
-        return fail(TRL_E_INVALID, "trl_alphasame_trunk16_pipe: %s", "bad argument");
-    hipLaunchKernelGGL(k_trunk16p, dim3(n_boards), dim3(TRUNK_THREADS), 0, (hipStream_t)stream, dev_boards, dev_packed, n_blocks,
-                       dev_out, dev_need);
     HIPCHK(hipGetLastError());
     return TRL_OK;
 }

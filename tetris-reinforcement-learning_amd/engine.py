@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "trl_env_legal_moves", "trl_env_legal_moves_algo", "trl_env_legal_dev", "trl_env_step", "trl_env_step_dev",
     "trl_env_rollout_random", "trl_last_kernel_ms",
     "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_expand_head", "trl_mcts_drain_records", "trl_mcts_drain_records_dev", "trl_mcts_get_stats",
-    "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16", "trl_alphasame_trunk16_need", "trl_alphasame_trunk16_split", "trl_alphasame_trunk16_pipe", "trl_trunk_wide_split", "trl_alphasame_trunk", "trl_resnet_trunk", "trl_graph_begin", "trl_graph_end", "trl_graph_end_many", "trl_graph_launch",
+    "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16", "trl_alphasame_trunk16_need", "trl_alphasame_trunk16_split", "trl_trunk_wide_split", "trl_alphasame_trunk", "trl_resnet_trunk", "trl_graph_begin", "trl_graph_end", "trl_graph_end_many", "trl_graph_launch",
     "trl_tower_overflow",
     "trl_mcts_select_need", "trl_mcts_fork_legal", "trl_mcts_expand_alphasame_masked", "trl_mcts_zcache", "trl_mcts_zcache_dim", "trl_mcts_expand_alphasame", "trl_mcts_expand_alphasame_select", "trl_mcts_restart",
 ]
@@ -147,7 +147,6 @@ def load_library(path=None):
                                                    C.c_void_p, C.c_int, C.c_int]
     L.trl_alphasame_trunk16_need.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.trl_alphasame_trunk16_split.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
-    L.trl_alphasame_trunk16_pipe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.trl_trunk_wide_split.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p]
     L.trl_alphasame_trunk16.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]

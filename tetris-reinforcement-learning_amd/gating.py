@@ -130,7 +130,7 @@ class Battle:
                     ended += 1
                     self.winners[int(r["slot"])] = int(r["winner"])
         st = self.engine.mcts_stats()
-        if self.nets is not None and any(getattr(m, "tower_mode", "").startswith("split") for m in self.nets):
+        if self.nets is not None and any(getattr(m, "tower_mode", "") == "split" for m in self.nets):
             st["tower_overflow"] = _eng.tower_overflow(self.device.index or 0, reset=True)     # the stream is synchronised
         if st["records_dropped"] or st["overflow"] or st.get("tower_overflow"):
             raise _eng.EngineError("device record buffer or tree capacity overflowed, or (tower_overflow) an activation left "

@@ -103,29 +103,6 @@ def _pack_conv3x3_split(w):
     return out.reshape(-1).view(torch.float32)
 
 
-def _pack_conv3x3_split3(w):
-    """the same for the tile-outermost 16-filter tower (k_trunk16p), which keeps a conv's whole weights in registers:
-    [K-step c][2^11 hi | hi | lo][lane][8 halves] -- the scaled hi half comes packed (exact: a power of two, |w| < 31), so the
-    kernel does not form it per tile.  float32 words (bit patterns), 3840 per conv."""
-    dev = w.device
-    lane = torch.arange(64, device=dev)
-    n, g = lane & 15, lane >> 4
-    w9 = w.reshape(16, 16, 9).to(torch.float32)
-    _check_split_range(w9)
-    out = torch.zeros((5, 3, 64, 8), dtype=torch.float16, device=dev)
-    for c in range(5):
-        tap = 2 * c + (g >> 1)
-        ok = tap <= 8
-        tapc = torch.clamp(tap, max=8)
-        for j in range(8):
-            v = torch.where(ok, w9[n, 8 * (g & 1) + j, tapc], torch.zeros(64, device=dev))
-            hi = v.to(torch.float16)
-            out[c, 0, :, j] = (hi.to(torch.float32) * SPLIT_SCALE).to(torch.float16)
-            out[c, 1, :, j] = hi
-            out[c, 2, :, j] = ((v - hi.to(torch.float32)) * SPLIT_SCALE).to(torch.float16)
-    return out.reshape(-1).view(torch.float32)
-
-
 def _pack_conv3x3_split_wide(w, f):
     """w [f out, f in, 3, 3] (f = 32 or 64) -> the weight operands of k_trunk_wide_s:
     [K-step = kg * 9 + tap][hi | lo][channel group][lane][8 halves]; lane (n = lane % 16, g = lane // 16) of group nt holds
@@ -200,8 +177,8 @@ class AlphaSame(nn.Module):
                                          "3": nn.Linear(mc.value_head_neurons, 1)})
         self._folded = None
         self.use_hip_trunk = True       # fused HIP tower when the net is on the GPU and filters is 16, 32 or 64
-        # "split" = k_trunk16p / k_trunk_wide_s (f16 matrix rate, operands split in two halves, fp32 accuracy),
-        # "split_k" = the same with the K-step-outermost 16-filter kernel k_trunk16s, "fp32" = k_trunk16 / k_trunk_wide
+        # "split" = k_trunk16s / k_trunk_wide_s (f16 matrix rate, operands split in two halves, fp32 accuracy),
+        # "fp32" = k_trunk16 / k_trunk_wide (fp32 matrix instructions)
         self.tower_mode = os.environ.get("TRL_TOWER", "split")
         self.eval()
 
@@ -228,8 +205,6 @@ class AlphaSame(nn.Module):
                                               and self.conv1.weight.is_cuda) else None
         # the 16-filter tower on the f16 matrix rate with split operands (k_trunk16s): fp32 accuracy, see csrc/trl_net.hip
         fd["packed_split"] = _split_or_none(lambda: self._pack_tower_split(fd)) if fd["packed_tower"] is not None else None
-        fd["packed_split3"] = (self._pack_tower_split(fd, pipe=True)
-                               if (fd["packed_split"] is not None and self.model_config.filters == 16) else None)
         self._folded = fd
         return self
 
@@ -253,20 +228,19 @@ class AlphaSame(nn.Module):
         parts += [s.reshape(-1), t.reshape(-1), wk.reshape(-1), bk.reshape(-1), torch.zeros(15 + (0 if f == 16 else 4096), device=dev)]
         return torch.cat([p.to(torch.float32) for p in parts]).contiguous()
 
-    def _pack_tower_split(self, fd, pipe=False):
+    def _pack_tower_split(self, fd):
         """packed weights of k_trunk16s: stem [16][25] fp32; per block s1[16] t1[16] convA (2560 words) ba[16] convB (2560);
-        tail s[16] t[16] wk[16] bk + padding.  pipe: the layout of k_trunk16p (3840 words per conv, 16 KiB of padding: the
-        kernel refills its weight registers with "the next conv's" during the last one too)"""
+        tail s[16] t[16] wk[16] bk + padding"""
         dev = self.conv1.weight.device
         f = self.model_config.filters
-        pack = (_pack_conv3x3_split3 if pipe else _pack_conv3x3_split) if f == 16 else (lambda w: _pack_conv3x3_split_wide(w, f))
+        pack = _pack_conv3x3_split if f == 16 else (lambda w: _pack_conv3x3_split_wide(w, f))
         parts = [self.conv1.weight.reshape(f, 25).reshape(-1)]
         for s1, t1, wa, ba, wb in fd["blocks"]:
             parts += [s1.reshape(-1), t1.reshape(-1), pack(wa), ba.reshape(-1), pack(wb)]
         s, t = fd["tail"]
         wk, bk = fd["k1"]
         # padding: the wide kernel prefetches the weights one K-step past the end of a conv
-        parts += [s.reshape(-1), t.reshape(-1), wk.reshape(-1), bk.reshape(-1), torch.zeros(15 + (0 if (f == 16 and not pipe) else 4096), device=dev)]
+        parts += [s.reshape(-1), t.reshape(-1), wk.reshape(-1), bk.reshape(-1), torch.zeros(15 + (0 if f == 16 else 4096), device=dev)]
         return torch.cat([p.to(torch.float32) if p.dtype != torch.float32 else p for p in parts]).contiguous()
 
     def load_state_dict(self, *a, **k):
@@ -286,7 +260,7 @@ class AlphaSame(nn.Module):
         fd = self._folded or self.prepare()._folded
         if fd["packed_tower"] is not None and self.use_hip_trunk:
             out = self._trunk_hip(boards, fd["packed_tower"])
-            if self.tower_mode in ("split", "split_k") and fd.get("packed_split") is not None and _split_overflowed(boards.device):
+            if self.tower_mode == "split" and fd.get("packed_split") is not None and _split_overflowed(boards.device):
                 _warn_split_range("AlphaSame.trunk")
                 self.tower_mode = "fp32"
                 out = self._trunk_hip(boards, fd["packed_tower"])
@@ -314,13 +288,8 @@ class AlphaSame(nn.Module):
             out = torch.empty((m, ROWS * COLS), dtype=torch.float32, device=boards.device)
         else:
             out = torch.zeros((m, ROWS * COLS), dtype=torch.float32, device=boards.device)
-        split = self._folded.get("packed_split") if (self._folded and self.tower_mode in ("split", "split_k")) else None
-        split3 = self._folded.get("packed_split3") if (self._folded and self.tower_mode == "split") else None
-        if split3 is not None and packed is self._folded["packed_tower"]:
-            rc = L.trl_alphasame_trunk16_pipe(x.data_ptr(), m, split3.data_ptr(), len(self.res_blocks), out.data_ptr(),
-                                              None if need is None else need.data_ptr(),
-                                              torch.cuda.current_stream(boards.device).cuda_stream)
-        elif split is not None and packed is self._folded["packed_tower"] and self.model_config.filters == 16:
+        split = self._folded.get("packed_split") if (self._folded and self.tower_mode == "split") else None
+        if split is not None and packed is self._folded["packed_tower"] and self.model_config.filters == 16:
             rc = L.trl_alphasame_trunk16_split(x.data_ptr(), m, split.data_ptr(), len(self.res_blocks), out.data_ptr(),
                                                None if need is None else need.data_ptr(),
                                                torch.cuda.current_stream(boards.device).cuda_stream)
@@ -536,7 +505,7 @@ class BaseResNet(nn.Module):
         x = boards.reshape(m, ROWS * COLS).contiguous()
         alloc = torch.empty if need is None else torch.zeros
         out = alloc((m, kout, ROWS * COLS), dtype=torch.float32, device=boards.device)
-        split = self._folded.get("packed_split") if (self._folded and self.tower_mode in ("split", "split_k")) else None
+        split = self._folded.get("packed_split") if (self._folded and self.tower_mode == "split") else None
         if split is not None and packed is self._folded["packed_tower"]:
             rc = L.trl_trunk_wide_split(x.data_ptr(), m, split.data_ptr(), self.model_config.filters, len(self.trunk), 1, kout,
                                         out.data_ptr(), None if need is None else need.data_ptr(),
@@ -586,7 +555,7 @@ class BaseResNet(nn.Module):
         if hip:
             if z is None:
                 z = self._tower_hip(grids.reshape(2 * n, ROWS * COLS), fd["packed_tower"])
-                if self.tower_mode in ("split", "split_k") and fd.get("packed_split") is not None and _split_overflowed(grids.device):
+                if self.tower_mode == "split" and fd.get("packed_split") is not None and _split_overflowed(grids.device):
                     _warn_split_range(type(self).__name__)
                     self.tower_mode = "fp32"
                     z = self._tower_hip(grids.reshape(2 * n, ROWS * COLS), fd["packed_tower"])

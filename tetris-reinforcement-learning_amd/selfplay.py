@@ -303,7 +303,7 @@ class SelfPlay:
         tree overflow (the remedy: network.tower_mode = 'fp32')"""
         self.stream.synchronize()
         st = self.engine.mcts_stats()
-        st["tower_overflow"] = _eng.tower_overflow(self.device.index or 0, reset=True) if getattr(self.net, "tower_mode", "").startswith("split") else 0
+        st["tower_overflow"] = _eng.tower_overflow(self.device.index or 0, reset=True) if getattr(self.net, "tower_mode", "") == "split" else 0
         return st
 
 
