@@ -96,11 +96,12 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
     net = trl.AlphaSame(trl.AlphaSameConfig(blocks=10, filters=16))
     cfg = trl.Config(visual=False, model="pytorch", model_config=trl.AlphaSameConfig(blocks=10, filters=16),
                      MAX_ITER=160, training=True)
-    # the slots tick in two groups on two streams (selfplay.SelfPlayGroups): the search kernels of one beside the tower of the other
+    # the slots tick in four groups on four streams (selfplay.SelfPlayGroups): the search kernels of some beside the towers of others
     sp = trl.make_self_play(cfg, net, n, seed=SEED, device=local_rank, streams=parallel.game_streams(rank, n),
                             auto_reset=True, use_graph=True, record_capacity=1 << 17)
     groups = len(getattr(sp, "parts", [sp]))
     sp.tick(args.mcts_warmup)
+    tk0 = time_tick_kernels(sp, reps=32)                    # the tick's two kernels, live, before ...
     sp.drain()
     st0 = sp.stats()
     barrier()
@@ -156,7 +157,8 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
         e1.record(sp.stream)
     e1.synchronize()
     trunk_ms = e0.elapsed_time(e1) / reps
-    tk = time_tick_kernels(sp)                              # (tower ms, search-kernel ms, slots) of one group's tick, live
+    tk1 = time_tick_kernels(sp, reps=32)                    # ... and after the timed region (the trees are deeper by then)
+    tk = None if (tk0 is None or tk1 is None) else (0.5 * (tk0[0] + tk1[0]), 0.5 * (tk0[1] + tk1[1]), tk1[2])
     my_rate = moves / elapsed
     elapsed, moves_total = parallel.reduce_job(elapsed, moves, dist, dev)
     _, sims_total = parallel.reduce_job(elapsed, sims, dist, dev)
@@ -187,7 +189,11 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
     if tk is not None:
         tower_tick_ms, search_ms, slots = tk
         tick_kernels = {"slots_per_launch": slots, "tower_ms": round(tower_tick_ms, 4), "k_expand_select_ms": round(search_ms, 4),
-                        "how": "HIP events on the slot group's stream, eager launches after the timed region, other group idle; medians"}
+                        "before_timed_region": {"tower_ms": round(tk0[0], 4), "k_expand_select_ms": round(tk0[1], 4)},
+                        "after_timed_region": {"tower_ms": round(tk1[0], 4), "k_expand_select_ms": round(tk1[1], 4)},
+                        "how": "HIP events on one slot group's stream round its two launches, 32 eager ticks (medians; the first 8 not counted) before and 32 "
+                               "after the timed region, the other groups idle; the figure is the mean of the two -- what the kernel "
+                               "trace's per-grid average of the same run shows (profiles/: kernel_trace_by_grid)"}
         pm = load_pmc("r03_mcts_pmc.json")
         search_bytes = SIM_BYTES * slots
         gbs = search_bytes / (search_ms * 1e-3) / 1e9
@@ -505,8 +511,10 @@ def bench_c1(args, local_rank):
 
 def time_tick_kernels(sp, reps=48):
     """HIP events around the two launches of the production tick (tower on the flagged boards, k_expand_select), issued
-    eagerly on the slot group's own stream after the timed region -- the other group idle, so each kernel has the chip to
-    itself.  Returns (tower ms, search ms, slots) as medians, or None when the tick is not the fused native one."""
+    eagerly on the slot group's own stream outside the timed region (called once before and once after it: the trees, and
+    with them the selection paths, are deeper afterwards) -- the other groups idle, so each kernel has the chip to itself;
+    the other groups then make the same number of ticks.  Returns (tower ms, search ms, slots) as medians, or None when
+    the tick is not the fused native one."""
     import statistics
     part = getattr(sp, "parts", [sp])[0]
     if not getattr(part, "fused_select", False):
@@ -527,6 +535,9 @@ def time_tick_kernels(sp, reps=48):
     part.ticks += reps
     tower = statistics.median(e0.elapsed_time(e1) for e0, e1, e2 in ev[8:])
     search = statistics.median(e1.elapsed_time(e2) for e0, e1, e2 in ev[8:])
+    for p in getattr(sp, "parts", [sp])[1:]:                # the other groups make the same number of ticks: lock-step rounds
+        p.tick(reps)
+        p.synchronize()
     return tower, search, part.n
 
 

@@ -680,3 +680,52 @@ def test_whole_searches_with_the_real_net_match_the_reference(golden_dir):
           (max(l1), float(np.mean(l1)), decided, n, same))
     assert decided >= 8
     assert max(l1) <= 16 and float(np.mean(l1)) <= 4.0
+
+
+def test_slot_group_streams_run_side_by_side():
+    """selfplay.concurrent_streams: the streams the slot groups tick on were checked to overlap pairwise (two HIP streams
+    can share a hardware queue, and then the groups' kernels take turns); drain_dev(then_tick=...) hands the records over
+    and lets the group go on ticking -- the same records as drain followed by tick"""
+    import time
+    from tetris_rl_amd import selfplay, engine
+    dev = torch.device("cuda", 0)
+    streams = selfplay.concurrent_streams(torch, dev, 4)
+    assert len(streams) == 4 and len({s.cuda_stream for s in streams}) == 4
+    cycles = int(2.0e6)                                          # ~1 ms of spinning per stream
+    torch.cuda._sleep(1000); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(streams[0]):
+        torch.cuda._sleep(cycles)
+    streams[0].synchronize()
+    one = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for s in streams:
+        with torch.cuda.stream(s):
+            torch.cuda._sleep(cycles)
+    for s in streams:
+        s.synchronize()
+    four = time.perf_counter() - t0
+    assert four < 2.0 * one, (one, four)                         # four spins side by side, not one after the other
+    torch.manual_seed(0)
+    mc = trl.AlphaSameConfig(blocks=2, filters=16)
+    net = trl.AlphaSame(mc).cuda().prepare()
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=16, training=True)
+    out = []
+    for overlap in (False, True):
+        sp = trl.SelfPlayGroups(cfg, net, 64, 2, seed=21)
+        recs = []
+        sp.tick(96)
+        for i in range(3):
+            if overlap:
+                t = sp.drain_dev(then_tick=96 if i < 2 else 0)
+            else:
+                t = sp.drain_dev()
+                if i < 2:
+                    sp.tick(96)
+            recs.append(t.cpu().numpy().view(engine.RECORD_DTYPE))
+        r = np.concatenate(recs)
+        out.append((r[np.lexsort((r["kind"], r["ply"], r["episode"], r["slot"]))], sp.stats()))
+    (a, sa), (b, sb) = out
+    assert sa["simulations"] == sb["simulations"] == 64 * 96 * 3 and len(a) == len(b) > 64
+    for f in ("slot", "episode", "ply", "kind", "winner", "chosen", "saved", "n_children", "state"):
+        assert np.array_equal(a[f], b[f]), f

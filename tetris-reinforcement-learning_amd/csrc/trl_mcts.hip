@@ -34,6 +34,9 @@ struct SlotCtl {
     int32_t n_nodes, n_states;
     int32_t leaf, leaf_kind, leaf_nlegal, leaf_state;
     int32_t overflow, leaf_parent_state;      // state index of the leaf's parent (-1 at the root)
+    // what the selection knows and the expand would otherwise re-load through dependent global reads: the leaf's side to
+    // move, and its parent's node index and child range (FPU refresh of the siblings, ai.py:536-565)
+    int32_t leaf_turn, par_node, par_first, par_n;
     int32_t depth, random_move;               // nodes on the selection path root .. leaf (DevMcts::path); this search picks a
     double  terminal_value;                   // random starting move (ai.py:1588-1608)
     double  rand_left;                        // num_random_moves still to play in this game
@@ -152,15 +155,17 @@ __device__ unsigned int g_slotprof[4096 * 16];  // the same per slot, for the la
 // ---- tick part A --------------------------------------------------------------------------------------
 // do_legal = 0: the legal-move search of the leaf is left to k_leaf_legal, which runs beside the net's tower on a second
 // stream (the tower needs the leaf's boards only); leaf_nlegal is filled in there.
+// `carry`: the slot's control block as the expand half of the same launch left it (LDS), instead of a store to and a load
+// from global memory
 template <class SH>
 static __device__ __forceinline__ void select_body(SH &sh, const DevMcts &M, trl_game_state *real, float *grids, float *vec,
-                                                   uint8_t *need, int do_legal) {
+                                                   uint8_t *need, int do_legal, const SlotCtl *carry = nullptr) {
     const int tid = threadIdx.x, slot = blockIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t nb = (size_t)slot * M.max_nodes;
     trl_game_state *pool = M.pool + (size_t)slot * M.cap_states;
     const trl_mcts_config &cfg = M.cfg;
     MPROF_T(ms0);
-    if (tid == 0) sh.ctl = M.ctl[slot];
+    if (tid == 0) sh.ctl = carry ? *carry : M.ctl[slot];
     __syncthreads();
     if (sh.ctl.phase == 2) {                       // idle slot: feed zeros to the net
         for (int i = tid; i < 2 * TRL_GRID_FLOATS; i += BLOCK)
@@ -203,12 +208,14 @@ static __device__ __forceinline__ void select_body(SH &sh, const DevMcts &M, trl
     // SELECT (ai.py:346-393): walk down by arg-max of Q + U, ties to the last child
     MPROF_T(ms1); MPROF_ADD(0, ms0, ms1);
     int node = 0, depth = 0;
+    int par_node = 0, par_first = 0, par_n = 0;
     while (true) {
         if (tid == 0 && depth < PATH_CAP) M.path[(size_t)slot * PATH_CAP + depth] = node;
         depth++;
         int n = M.t.nchild[nb + node];
         if (n == 0) break;
         const int first = M.t.first[nb + node];
+        par_node = node; par_first = first; par_n = n;
         const int parent_visits = M.t.visit[nb + node];
         const double sqrt_parent = sqrt((double)parent_visits);
         const double u_scale = cfg.cpuct * sqrt_parent / cfg.dpuct;
@@ -328,6 +335,7 @@ static __device__ __forceinline__ void select_body(SH &sh, const DevMcts &M, trl
         c.iter += 1;
         c.leaf = node; c.leaf_kind = kind; c.leaf_nlegal = nlegal; c.leaf_state = sidx; c.leaf_parent_state = pstate;
         c.depth = depth;
+        c.leaf_turn = g.turn; c.par_node = par_node; c.par_first = par_first; c.par_n = par_n;
         if (need) {
             // which boards need the tower: a move changes only the mover's board (game.py:66-118), so the side to
             // move at the leaf keeps the tower output its board had in the parent position (trl_mcts_zcache)
@@ -418,7 +426,7 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
     if (MODE == 2 && kind != 2) {
         // complete z from the cache, store the leaf's entry, build x = [z_own, own extras, oside(z_opp), opp extras, colour]
         const float *z = policy, *vecp = values + (size_t)slot * TRL_VEC_FLOATS;
-        const int q = pool[sh.ctl.leaf_state].turn, ps = sh.ctl.leaf_parent_state;
+        const int q = sh.ctl.leaf_turn, ps = sh.ctl.leaf_parent_state;        // (= pool[leaf_state].turn)
         float *zc = M.zcache + ((size_t)slot * M.cap_states) * 800;
         float *mine = zc + (size_t)sh.ctl.leaf_state * 800;
         for (int i = tid; i < 400; i += NT) {
@@ -501,16 +509,17 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
                 float xr[9];
 #pragma unroll
                 for (int t = 0; t < 9; t++) xr[t] = (lane + 64 * t < 521) ? sh.xs[lane + 64 * t] : 0.f;
-                for (int k0 = wave * 4; k0 < n; k0 += NW * 4) {          // 4 moves per wave and step: 36 loads in flight
-                    float acc[4]; int idx[4];
+                constexpr int RS = 6;                                      // moves per wave and step: 54 loads in flight
+                for (int k0 = wave * RS; k0 < n; k0 += NW * RS) {
+                    float acc[RS]; int idx[RS];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < RS; u++) {
                         int k = k0 + u < n ? k0 + u : n - 1;
                         int m = lm[k];
                         idx[u] = (TRL_MOVE_PLANE(m) * TRL_POLICY_ROWS + TRL_MOVE_ROW(m)) * TRL_POLICY_COLS + TRL_MOVE_COL(m);
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < RS; u++) {
                         const float *row = head_w + (size_t)idx[u] * 521;
                         float a = 0.f;
 #pragma unroll
@@ -518,7 +527,7 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
                         acc[u] = a;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < RS; u++) {
                         float a = acc[u];
 #pragma unroll
                         for (int d = 32; d >= 1; d >>= 1) a += __shfl_xor(a, d, 64);
@@ -648,7 +657,7 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
         // load per level) is replaced by one lane per level over the path k_select recorded
         const double bval = tanh_range ? -value : 1.0 - value;
         const double pos = bval, neg = tanh_range ? -bval : 1.0 - bval;
-        const int final_turn = M.t.turn[nb + leaf];
+        const int final_turn = sh.ctl.leaf_turn;                               // (= M.t.turn[nb + leaf])
         const int depth = sh.ctl.depth;
         if (depth <= PATH_CAP) {
             if (tid < depth) {
@@ -670,9 +679,9 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
         __syncthreads();
         // FPU refresh: the parent's unvisited children restart from (1 - Q_parent) - reduction * sqrt(sum of the visited
         // children's priors), the sum taken in float32 and in child order (ai.py:536-565)
-        const int par = (leaf != 0 && cfg.fpu_reduction) ? M.t.parent[nb + leaf] : 0;
+        const int par = (leaf != 0 && cfg.fpu_reduction) ? sh.ctl.par_node : 0;   // (= M.t.parent[nb + leaf])
         if (par != 0) {
-            const int n = M.t.nchild[nb + par], first = M.t.first[nb + par];
+            const int n = sh.ctl.par_n, first = sh.ctl.par_first;              // (= nchild / first of the parent)
             for (int k = tid; k < n; k += BLOCK)
                 sh.pf[k] = (M.t.visit[nb + first + k] > 0) ? (float)M.t.prior[nb + first + k] : -1.f;   // priors are > 0
             __syncthreads();
@@ -857,13 +866,15 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(4
                                                          const float *head_w, const float *head_b, HeadsDev H, float *grids,
                                                          uint8_t *need) {
     __shared__ union U { ExpandShared e; SelectShared s; __device__ U() {} } sh;
+    __shared__ SlotCtl carry;                      // the slot's control block from the expand half to the select half
     // latency-bound (two waves per slot, long dependent chains): when the other slot group's tower shares the SIMD, these
     // waves go first -- they issue rarely, so the tower loses little and the search chain of the tick gets shorter
     __builtin_amdgcn_s_setprio(SEARCH_PRIO);
     expand_body<2, FUSED_THREADS>(sh.e, M, real, vec, z, head_w, head_b, 521, H);
     if (threadIdx.x >= BLOCK) return;              // (slots that were not expanding: the extra waves end here)
-    __syncthreads();                               // the tree and the slot's control block are in memory; the LDS block changes hands
-    select_body(sh.s, M, real, grids, vec, need, 1);
+    if (threadIdx.x == 0) carry = sh.e.ctl;        // as stored to M.ctl[slot] (or as loaded, for a slot that was not searching)
+    __syncthreads();                               // the tree is in memory; the LDS block changes hands
+    select_body(sh.s, M, real, grids, vec, need, 1, &carry);
 }
 
 // tower-output cache.  z: [2][n][400] as written by the tower for the boards flagged by k_select.  Afterwards
