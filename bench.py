@@ -108,17 +108,20 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
     t0 = time.perf_counter()
     done = 0
     drained = []
-    k = min(512, args.mcts_ticks)
-    sp.tick(k)
-    done = k
-    while True:
-        nxt = min(512, args.mcts_ticks - done)
-        # records leave the search's buffer inside the timed region and stay in HBM; a slot group that has handed its
-        # records over goes on with the next chunk of ticks while the next group is drained
-        drained.append(sp.drain_dev(then_tick=nxt))
-        done += nxt
-        if nxt == 0:
-            break
+    pending = None
+    while done < args.mcts_ticks:
+        # records leave the search's buffers inside the timed region and stay in HBM: after every chunk of ticks a drain is
+        # queued on each slot group's stream (trl_mcts_drain_records_async: no host round trip), the next chunk right
+        # behind it; the host picks the previous chunk's records up on a side stream while the device goes on
+        k = min(512, args.mcts_ticks - done)
+        sp.tick(k)
+        ticket = sp.drain_async()
+        if pending is not None:
+            drained.append(sp.take(pending)[0])
+        pending = ticket
+        done += k
+    if pending is not None:
+        drained.append(sp.take(pending)[0])
     sp.synchronize()
     t_ticks = time.perf_counter() - t0
     # C4: the one exchange step of the path -- every rank's packed (state, pi, z) move records to rank 0: over RCCL
@@ -270,9 +273,6 @@ def bench_c5(args, rank, local_rank, world, dist, dev, barrier):
     sp.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if os.environ.get("TRL_BENCH_DEBUG"):
-        sys.stderr.write("[bench] C3 timed region %.1f ms: ticks + drains %.1f ms, gather + host copy %.1f ms\n"
-                         % (elapsed * 1e3, t_ticks * 1e3, (elapsed - t_ticks) * 1e3))
     st1 = sp.stats()
     if st1["overflow"] or st1["records_dropped"] or st1.get("tower_overflow"):
         raise SystemExit("tree / record capacity (or the split towers' activation range) overflowed during the C5 benchmark: results invalid")
@@ -526,7 +526,7 @@ def time_tick_kernels(sp, reps=48):
     with torch.cuda.stream(part.stream):
         for e0, e1, e2 in ev:
             e0.record(part.stream)
-            part.net.tower_need(part.grids, part.need, out=part.z)
+            part._tower()
             e1.record(part.stream)
             part.engine.mcts_expand_alphasame_select(part.z.data_ptr(), part.vec.data_ptr(), part.heads, part.grids.data_ptr(),
                                                      part.need.data_ptr())

@@ -334,6 +334,17 @@ int  trl_mcts_expand_alphasame_select(trl_engine *h, const float *dev_z, float *
  * game states (trl_env_set_state / trl_env_reset / trl_env_step) while a selection made by the call above is pending
  * discards it with this call and selects again (trl_mcts_select_need).                                              */
 int  trl_mcts_restart(trl_engine *h);
+/* The legal-move search of the leaf (get_move_matrix + get_move_list, ai.py:414-417) as part of the TOWER launch of the
+ * tick instead of the selection: it needs the leaf's position only, exactly like the tower, so its workgroups run in the
+ * registers the tower's boards leave free and the few searches that take four times as long as the others (T pieces
+ * whose T-spin sub-plane depends on the walk's order) no longer set the length of the search kernel's launch.
+ * on = 1: trl_mcts_select_need and trl_mcts_expand_alphasame_select (called with need flags) leave the search out; the
+ * next call for this engine must be trl_mcts_tower16_legal, which runs the split 16-filter tower (the contract of
+ * trl_alphasame_trunk16_split, on the engine's stream) with the search's workgroups in front.  Any other order fails
+ * with TRL_E_STATE.  'convolutional' generator only; not together with trl_mcts_fork_legal. */
+int  trl_mcts_legal_in_tower(trl_engine *h, int on);
+int  trl_mcts_tower16_legal(trl_engine *h, const float *dev_boards, int n_boards, const float *dev_packed, int n_blocks,
+                            float *dev_out, const uint8_t *dev_need);
 /* the same for the slots with dev_slot_mask[slot] == want only (uint8 per slot): matches between two networks run one
  * launch per network (battle_networks, ai.py:1975-2052: a player's searches use that player's network); `last` = 1
  * on the launch that completes the tick. */
@@ -344,6 +355,16 @@ int  trl_mcts_drain_records(trl_engine *h, trl_record *host_out, int cap, int *n
 /* the same into a DEVICE buffer of `cap` records (the gather of the records to rank 0 then runs GPU -> GPU over
  * RCCL / xGMI without touching the sender's host); the copy is queued on the engine's stream, the count is returned */
 int  trl_mcts_drain_records_dev(trl_engine *h, trl_record *dev_out, int cap, int *n_out);
+/* the same without a host round trip: the pending records are APPENDED to dev_out behind the dev_head[0] records already
+ * there (room for `cap` in all; what does not fit is counted in records_dropped), every record's slot raised by
+ * slot_offset (a slot group's first global slot), and the pending count cleared -- all queued on the engine's stream, the
+ * call returns at once.  dev_head: uint64[9] on the device, zeroed by the caller before the first call;
+ * [0] = records in dev_out, [1..8] = the search counters as of this drain: simulations, moves, games, records_dropped,
+ * max_nodes_used, overflow, ticks, reserved.  A job that ticks in chunks queues the next chunk behind this call and
+ * reads dev_head / dev_out of the previous one on another stream: the device never waits for the host (the reference's
+ * loop appends a move's record to the game's list as it is played, ai.py:1613-1660; this is that list leaving the
+ * search's buffer). */
+int  trl_mcts_drain_records_async(trl_engine *h, trl_record *dev_out, int cap, uint64_t *dev_head, uint32_t slot_offset);
 int  trl_mcts_get_stats(trl_engine *h, trl_mcts_stats *host_out);
 /* leaf positions of the current tick (after trl_mcts_select), n_games canonical states; and per
  * slot {simulation index, simulations of this search, leaf kind 0 expand / 1 eval only / 2 terminal,

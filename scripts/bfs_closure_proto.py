@@ -104,6 +104,7 @@ def closure_search(rows, ptype, need_spawn):
     a_other = [[0] * MAP_W for _ in range(4)]
     done_src = [[0] * MAP_W for _ in range(4)]
     rounds = iters = 0
+    snaps = []                                      # reach after the fixed point of round 0, 1 (generation <= 0, <= 1 cells)
     while True:
         # closure under down / left / right inside each rotation state
         while True:
@@ -120,6 +121,8 @@ def closure_search(rows, ptype, need_spawn):
                     reach[rot][mx] = r
             if not changed:
                 break
+        if len(snaps) < 2:
+            snaps.append([row[:] for row in reach])
         if ptype == PO:
             break
         # kicks from the edge cells that have not sent theirs yet
@@ -155,6 +158,9 @@ def closure_search(rows, ptype, need_spawn):
                     reach[rot][mx] |= n
         if not new_any:
             break
+    resolved = 0
+    if ptype == PT and RESOLVE_MIXED:
+        resolved = resolve_mixed(valid, edge, sel, ktab, reach, snaps, a_last, a_other, stuck)
     # column form -> the row planes of MgScratch
     present = [[0] * MAP_H for _ in range(4)]
     flagp = [[0] * MAP_H for _ in range(4)]
@@ -174,7 +180,102 @@ def closure_search(rows, ptype, need_spawn):
                     flagp[rot][my] |= 1 << mx
                 if (f1 >> my) & 1:
                     ulp[rot][my] |= 1 << mx
-    return present, flagp, ulp, mixed, rounds, iters
+    return present, flagp, ulp, mixed, rounds, iters, resolved
+
+
+RESOLVE_MIXED = True
+
+
+def resolve_mixed(valid, edge, sel, ktab, reach, snaps, a_last, a_other, stuck):
+    """Mixed T cells whose winner follows from the first two generations of the walk, without walking: the walk's FIFO order
+    is the order of the pushes, and as long as every rotation state's generation-1 cells are flooded by ONE queue item (the
+    first one pushed into that state from the spawn region) the time of every flagged write is a tuple of map coordinates:
+      * arrival from a generation-0 source (spawn region, rotation 0) on a cell first visited in generation 1: written when
+        the pushed item is popped: (1, key0(source), 0)                     key0 = (row, column, direction) of the source
+      * arrival from a generation-1 source s on a cell that has been visited by then (cells of the spawn region, or of a
+        rotation state whose item was popped before s's): written while s's state is flooded: (1, seedkey(rot s), 1, key(s))
+      * ... on a cell not visited yet: pushed, written in generation 2: (2, seedkey(rot s), key(s))
+    The last write wins (move_generation.py:671-677).  Clears the losing class's bit of every cell it settles; returns the
+    number of cells settled, -1 if some mixed cell is outside these cases (deeper generations, several floods per state):
+    the ordered walk is needed then."""
+    r0 = snaps[0]
+    r1 = snaps[1] if len(snaps) > 1 else reach
+    mixed_cells = [(rot, mx, my) for rot in range(4) for mx in range(MAP_W) for my in range(MAP_H)
+                   if ((a_last[rot][mx] & a_other[rot][mx] & stuck[rot][mx]) >> my) & 1]
+    if not mixed_cells:
+        return 0
+    # the first push into each rotation state from the spawn region (rotation 0): sources in (row, column, direction) order
+    seedkey, seedcell = {}, {}
+    for d in range(3):
+        nrot = d + 1
+        best = None
+        for mx in range(MAP_W):
+            src = r0[0][mx] & edge[0][mx]
+            for ki, (kx, ky) in enumerate(ktab[d]):
+                moved = src & sel[0][mx][d][ki]
+                if moved:
+                    my = (moved & -moved).bit_length() - 1
+                    cand = ((my << 6) | (mx << 2) | d, (nrot, mx + kx, my - ky))
+                    if best is None or cand[0] < best[0]:
+                        best = cand
+        if best is not None:
+            seedkey[nrot], seedcell[nrot] = best
+    # one flood per rotation state in generation 1?
+    dm = [[0] * MAP_W for _ in range(4)]
+    for nrot, (_, tx, ty) in seedcell.items():
+        dm[nrot][tx] = 1 << ty
+    while True:
+        changed = False
+        for rot in range(1, 4):
+            for mx in range(MAP_W):
+                r = down_fill(valid[rot][mx], dm[rot][mx])
+                r |= ((dm[rot][mx - 1] if mx > 0 else 0) | (dm[rot][mx + 1] if mx + 1 < MAP_W else 0)) & valid[rot][mx]
+                if r != dm[rot][mx]:
+                    changed = True
+                dm[rot][mx] = r
+        if not changed:
+            break
+    for rot in range(1, 4):
+        for mx in range(MAP_W):
+            if dm[rot][mx] != r1[rot][mx]:
+                return -1
+    settled = 0
+    for rK, xK, yK in mixed_cells:
+        inK = ((r0[0][xK] if rK == 0 else r1[rK][xK]) >> yK) & 1
+        if not inK:
+            return -1
+        best = None
+        for rs in range(4):
+            if rs == rK:
+                continue
+            d = (rK - rs - 1) & 3
+            kl = ktab[rs * 3 + d]
+            for ki, (kx, ky) in enumerate(kl):
+                sx, sy = xK - kx, yK + ky
+                if not (0 <= sx < MAP_W and 0 <= sy < MAP_H):
+                    continue
+                if not ((reach[rs][sx] & edge[rs][sx] & sel[rs][sx][d][ki]) >> sy) & 1:
+                    continue
+                ulk = d != 1 and ki == len(kl) - 1
+                skey = (sy << 6) | (sx << 2) | d
+                if rs == 0:
+                    if not (r0[0][sx] >> sy) & 1:
+                        return -1
+                    t = (1 << 40) | (skey << 21)
+                else:
+                    if not (r1[rs][sx] >> sy) & 1:
+                        return -1
+                    visited = rK == 0 or seedkey[rK] < seedkey[rs]
+                    t = ((1 << 40) | (seedkey[rs] << 21) | (1 << 20) | skey) if visited else ((2 << 40) | (seedkey[rs] << 21) | skey)
+                if best is None or t > best[0]:
+                    best = (t, ulk)
+        assert best is not None
+        if best[1]:
+            a_other[rK][xK] &= ~(1 << yK)
+        else:
+            a_last[rK][xK] &= ~(1 << yK)
+        settled += 1
+    return settled
 
 
 def placements_to_moves(present, flagp, ulp, ptype):
@@ -221,8 +322,8 @@ def legal_for_state(st):
         r = closure_search(rows, t, need_spawn)
         if r is None:
             continue
-        present, flagp, ulp, mixed, rounds, iters = r
-        info.append((t, mixed, rounds, iters))
+        present, flagp, ulp, mixed, rounds, iters, resolved = r
+        info.append((t, mixed, rounds, iters, resolved))
         moves += placements_to_moves(present, flagp, ulp, t)
     return sorted(moves), info
 
@@ -232,7 +333,7 @@ def main():
     off = np.concatenate([[0], np.cumsum(d["legal_counts"])])
     n = len(d["states"])
     step = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-    bad = t_searches = t_mixed = searches = 0
+    bad = t_searches = t_mixed = searches = t_resolved = 0
     rounds_hist, iters_hist = [], []
     for i in range(0, n, step):
         st = d["states"][i]
@@ -240,8 +341,9 @@ def main():
             continue
         want = d["legal_flat"][off[i]:off[i + 1]].tolist()
         got, info = legal_for_state(st)
-        has_mixed = any(m for _, m, _, _ in info)
-        for t, m, r, it in info:
+        has_mixed = any(m for _, m, _, _, _ in info)
+        for t, m, r, it, rs in info:
+            t_resolved += int(rs > 0 and not m)
             searches += 1
             rounds_hist.append(r); iters_hist.append(it)
             if t == PT:
@@ -251,14 +353,14 @@ def main():
             bad += 1
             print("MISMATCH at state", i, len(got), len(want))
     print("env_traces: %d states checked (every %d-th), %d searches, %d mismatches outside mixed T searches; "
-          "T searches %d, of them mixed %d (%.1f %%)" % (len(range(0, n, step)), step, searches, bad, t_searches, t_mixed,
-                                                         100.0 * t_mixed / max(t_searches, 1)))
+          "T searches %d, of them left to the ordered walk %d (%.1f %%), settled by resolve_mixed %d" %
+          (len(range(0, n, step)), step, searches, bad, t_searches, t_mixed, 100.0 * t_mixed / max(t_searches, 1), t_resolved))
     print("kick rounds per search: mean %.2f max %d; closure iterations per search: mean %.1f max %d" %
           (np.mean(rounds_hist), max(rounds_hist), np.mean(iters_hist), max(iters_hist)))
     # the T fixtures: positions on which the reference's two generators disagree (complex T boards) and 120 where they agree
     d = np.load(os.path.join(GOLD, "movegen_t.npz"))
     offc = np.concatenate([[0], np.cumsum(d["conv_counts"])])
-    bad = mixed = 0
+    bad = mixed = settled = 0
     for i in range(len(d["rows"])):
         rows = d["rows"][i].astype(int).tolist()
         piece, held, q0 = int(d["piece"][i]), int(d["held"][i]), int(d["q0"][i])
@@ -269,13 +371,14 @@ def main():
             if r is None:
                 continue
             anym |= r[3]
+            settled += int(r[6] > 0 and not r[3])
             moves += placements_to_moves(r[0], r[1], r[2], t)
         mixed += int(anym)
         if sorted(moves) != d["conv_flat"][offc[i]:offc[i + 1]].tolist() and not anym:
             bad += 1
             print("MISMATCH in movegen_t case", i)
-    print("movegen_t: %d cases, %d mismatches outside mixed searches, %d with a mixed T cell (%.1f %%)" %
-          (len(d["rows"]), bad, mixed, 100.0 * mixed / len(d["rows"])))
+    print("movegen_t: %d cases, %d mismatches outside the searches left to the ordered walk, %d left to it (%.1f %%), %d searches "
+          "settled by resolve_mixed" % (len(d["rows"]), bad, mixed, 100.0 * mixed / len(d["rows"]), settled))
 
 
 if __name__ == "__main__":

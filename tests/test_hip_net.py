@@ -596,8 +596,9 @@ def _sorted_records(sp):
 
 def test_production_tick_at_c3_size(monkeypatch):
     """BASELINE config C3 as the bench times it -- 1024 slots, AlphaSame(10, 16) on k_trunk16s, training=True, the fused
-    expand + select launch inside eight-tick graphs, four slot groups on four streams -- for 480 ticks, against the same
-    job run as two groups and as one group, with the three-kernel tick (TRL_FUSE_SELECT=0) and with one tick per graph (TRL_GRAPH_TICKS=1):
+    expand + select launch inside eight-tick graphs, the leaves' legal-move search in the tower launch, four slot groups on
+    four streams -- for 480 ticks, against the same job run as two groups and as one group, with the legal-move search in
+    the selection (TRL_LEGAL_IN_TOWER=0), with the three-kernel tick (TRL_FUSE_SELECT=0) and with one tick per graph (TRL_GRAPH_TICKS=1):
     identical records, no overflow of any kind, and the invariants of a search (ai.py:299-659) on every record."""
     from tetris_rl_amd import selfplay
     torch.manual_seed(0)
@@ -606,13 +607,17 @@ def test_production_tick_at_c3_size(monkeypatch):
     cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=160, training=True)
     n, ticks, seed = 1024, 480, 20260630
     out = []
-    for groups, fuse, per_graph in ((4, True, 8), (2, True, 8), (1, True, 8), (1, False, 8), (1, True, 1)):
+    # (groups, fused expand + select, ticks per graph, the leaves' legal-move search inside the tower launch)
+    for groups, fuse, per_graph, in_tower in ((4, True, 8, True), (2, True, 8, True), (1, True, 8, True), (1, True, 8, False),
+                                              (1, False, 8, False), (1, True, 1, True)):
         monkeypatch.setattr(selfplay, "FUSE_SELECT", fuse)
         monkeypatch.setattr(selfplay, "GRAPH_TICKS", per_graph)
+        monkeypatch.setattr(selfplay, "LEGAL_IN_TOWER", in_tower)
         kw = dict(seed=seed, auto_reset=True, record_capacity=1 << 15)
         sp = trl.SelfPlayGroups(cfg, net, n, groups, **kw) if groups > 1 else trl.SelfPlay(cfg, net, n, **kw)
         part = getattr(sp, "parts", [sp])[0]
         assert part.fused_select == fuse and part.native_graph and part.heads is not None and part.net.tower_mode == "split"
+        assert part.legal_in_tower == (fuse and in_tower)
         sp.tick(ticks)
         st = sp.stats()
         assert st["overflow"] == 0 and st["records_dropped"] == 0 and st["tower_overflow"] == 0
@@ -729,3 +734,108 @@ def test_slot_group_streams_run_side_by_side():
     assert sa["simulations"] == sb["simulations"] == 64 * 96 * 3 and len(a) == len(b) > 64
     for f in ("slot", "episode", "ply", "kind", "winner", "chosen", "saved", "n_children", "state"):
         assert np.array_equal(a[f], b[f]), f
+
+
+def test_records_leave_without_a_host_round_trip():
+    """SelfPlay.drain_async / take (trl_mcts_drain_records_async): the next chunk of ticks is queued behind the drain, the
+    records of the previous chunk are picked up on a side stream -- the same records, slot numbers and counters as the
+    drain that waits for the stream; and what does not fit the caller's buffer is counted as dropped"""
+    from tetris_rl_amd import engine, selfplay
+    torch.manual_seed(0)
+    mc = trl.AlphaSameConfig(blocks=2, filters=16)
+    net = trl.AlphaSame(mc).cuda().prepare()
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=16, training=True)
+    size = engine.RECORD_DTYPE.itemsize
+
+    def sorted_records(parts):
+        r = np.concatenate(parts)
+        return r[np.lexsort((r["kind"], r["ply"], r["episode"], r["slot"]))]
+
+    sp = trl.SelfPlayGroups(cfg, net, 64, 2, seed=21)
+    plain = []
+    for i in range(4):
+        sp.tick(96)
+        plain.append(sp.drain())
+    a, sa = sorted_records(plain), sp.stats()
+
+    sp = trl.SelfPlayGroups(cfg, net, 64, 2, seed=21)
+    piped, counters, pending = [], [], None
+    for i in range(4):
+        sp.tick(96)
+        ticket = sp.drain_async()
+        if pending is not None:
+            t, st = sp.take(pending)
+            piped.append(t.cpu().numpy().view(engine.RECORD_DTYPE))
+            counters.append(st)
+        pending = ticket
+    with pytest.raises(RuntimeError):
+        sp.parts[0].drain_async(), sp.parts[0].drain_async()           # a third ticket with two outstanding
+    sp.parts[0]._acc_busy = [False, False]                              # (the refused draw changed nothing else)
+    t, st = sp.take(pending)
+    piped.append(t.cpu().numpy().view(engine.RECORD_DTYPE))
+    counters.append(st)
+    b, sb = sorted_records(piped), sp.stats()
+    assert len(a) == len(b) > 64 and a.tobytes() == b.tobytes()
+    assert [c["ticks"] for c in counters] == [96, 192, 288, 384]
+    assert counters[-1]["simulations"] == sa["simulations"] == sb["simulations"] == 64 * 96 * 4
+    assert counters[-1]["moves"] == sa["moves"] and counters[-1]["games"] == sa["games"]
+    assert sorted(set(b["slot"].tolist())) == list(range(64))          # the second group's records carry global slots
+
+    # a caller's buffer with room for 5 records: 5 arrive, the rest are counted as dropped; appends go behind the head
+    one = trl.SelfPlay(cfg, net, 32, seed=21)
+    one.tick(96)
+    buf = torch.zeros(5 * size, dtype=torch.uint8, device="cuda")
+    head = torch.zeros(selfplay.DRAIN_HEAD_WORDS, dtype=torch.int64, device="cuda")
+    one.engine.mcts_drain_records_async(buf.data_ptr(), 5, head.data_ptr(), 1000)
+    one.synchronize()
+    h = head.cpu().numpy()
+    ref = trl.SelfPlay(cfg, net, 32, seed=21)
+    ref.tick(96)
+    want = ref.drain()
+    assert len(want) > 5 and h[0] == 5 and h[1 + 3] == len(want) - 5
+    got = buf.cpu().numpy().view(engine.RECORD_DTYPE)
+    assert set((got["slot"].astype(np.int64) - 1000).tolist()) <= set(range(32))      # slot_offset was added
+    assert one.drain().size == 0                                       # the pending count was cleared
+
+
+def test_legal_moves_in_the_tower_launch_keep_their_order():
+    """trl_mcts_legal_in_tower: a selection that left its legal-move search to the tower launch must be followed by
+    trl_mcts_tower16_legal -- an expand or another selection before it is refused (TRL_E_STATE), and so is the tower call
+    without the mode; after the tower launch the leaves' move lists are the ones the selection itself would have made"""
+    from tetris_rl_amd import engine, selfplay
+    torch.manual_seed(0)
+    mc = trl.AlphaSameConfig(blocks=2, filters=16)
+    net = trl.AlphaSame(mc).cuda().prepare()
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=16, training=True)
+    a = trl.SelfPlay(cfg, net, 48, seed=5, use_graph=False)
+    b = trl.SelfPlay(cfg, net, 48, seed=5, use_graph=False)
+    assert net.supports_tower_legal
+    with pytest.raises(engine.EngineError):                        # the mode is off
+        net.tower_legal(a.engine, a.grids, a.need, out=a.z)
+    a.engine.mcts_legal_in_tower(True)
+    for sp in (a, b):
+        with torch.cuda.stream(sp.stream):
+            sp.engine.mcts_select_need(sp.grids.data_ptr(), sp.vec.data_ptr(), sp.need.data_ptr())
+    with torch.cuda.stream(a.stream):
+        with pytest.raises(engine.EngineError):                    # the leaves have no move lists yet
+            a.engine.mcts_expand_alphasame(a.z.data_ptr(), a.vec.data_ptr(), a.heads)
+        with pytest.raises(engine.EngineError):
+            a.engine.mcts_select_need(a.grids.data_ptr(), a.vec.data_ptr(), a.need.data_ptr())
+        with pytest.raises(engine.EngineError):
+            a.engine.mcts_legal_in_tower(False)
+    for t in range(40):
+        with torch.cuda.stream(a.stream):
+            net.tower_legal(a.engine, a.grids, a.need, out=a.z)
+            a.engine.mcts_expand_alphasame_select(a.z.data_ptr(), a.vec.data_ptr(), a.heads, a.grids.data_ptr(), a.need.data_ptr())
+        with torch.cuda.stream(b.stream):
+            net.tower_need(b.grids, b.need, out=b.z)
+            b.engine.mcts_expand_alphasame_select(b.z.data_ptr(), b.vec.data_ptr(), b.heads, b.grids.data_ptr(), b.need.data_ptr())
+    with torch.cuda.stream(a.stream):
+        net.tower_legal(a.engine, a.grids, a.need, out=a.z)        # the pending selection's lists
+    a.synchronize(), b.synchronize()
+    sa, ia = a.engine.mcts_leaf_states()
+    sb, ib = b.engine.mcts_leaf_states()
+    assert np.array_equal(sa, sb) and np.array_equal(ia, ib)
+    ra, rb = a.drain(), b.drain()                                  # (in the order the slots' workgroups got there)
+    ra, rb = (r[np.lexsort((r["kind"], r["ply"], r["episode"], r["slot"]))] for r in (ra, rb))
+    assert len(ra) == len(rb) > 48 and ra.tobytes() == rb.tobytes()

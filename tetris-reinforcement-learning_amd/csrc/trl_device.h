@@ -404,6 +404,7 @@ struct alignas(8) CsScratch {
     uint64_t vcol[4 * 20];           // valid[rot] column mx at index rot * 20 + mx + 2; the other entries are zero guards
     uint64_t arr[2][4 * 20];         // kick arrivals, same indexing: [1] through the last kick of a list (T, not 180), [0] others
     uint64_t kick[12];               // this piece's kick lists, [rot * 3 + dir - 1] (six registers less across the fixed point)
+    uint64_t snap[64];               // T: per lane, the cells reached after generation 0 (rotation 0) / 1 (the others): resolve_mixed_wave
 };
 static_assert(sizeof(CsScratch) <= sizeof(MgScratch), "the closure search's scratch shares the ordered walk's memory");
 
@@ -432,7 +433,164 @@ __device__ __forceinline__ void scatter_column(uint16_t *plane, uint64_t col, in
     }
 }
 
-// returns the number of placements, or -1: a T search whose sub-planes depend on the walk's order (take the ordered walk)
+// (butterfly through ds_bpermute with the caller's lane index: __shfl_xor derives the lane from mbcnt, a value the compiler
+// then keeps for the whole launch)
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v, int lane) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        const int src = (lane ^ off) << 2;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(v >> 32));
+        const uint64_t o = (uint64_t)lo | ((uint64_t)hi << 32);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 32; off; off >>= 1) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ off) << 2, (int)v);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// Mixed T cells (flagged arrivals through a last kick AND through another kick: the last flagged writer decides the
+// sub-plane, move_generation.py:671-677) whose last writer follows from the first two generations of the walk, without
+// walking.  The FIFO's order is the order of the pushes; the spawn region (generation 0, rotation 0) is one flood, so the
+// generation-1 items are ordered by the (row, column, direction) of their source cell in it, and as long as each of the
+// other three rotation states' generation-1 cells are flooded by ONE item (the first one pushed into that state), the time
+// of a flagged write is a tuple of map coordinates:
+//   arrival from a generation-0 source on a cell first visited in generation 1: written when the pushed item is popped
+//       (1, key(source), 0)                                               key = (row, column, direction)
+//   arrival from a generation-1 source s on a cell already visited by then -- a cell of the spawn region, or of a state
+//   whose first item was pushed before s's state's -- written while s's state is flooded
+//       (1, seedkey(rot s), 1, key(s))                                    seedkey = key of the first push into the state
+//   ... on a cell not visited yet: pushed, written when popped in generation 2:   (2, seedkey(rot s), key(s))
+// The latest write wins.  A search with a mixed cell outside these cases (a cell or a source first reached in a later
+// generation, a state flooded in several pieces) is left to the ordered walk (returns false): 4 % of the T searches of the
+// fixture games instead of 21 %.  scripts/bfs_closure_proto.py: resolve_mixed, checked against every fixture list.
+// C.snap holds the generation snapshots; the three planes (not written yet) lend their memory: the caller has left every
+// lane's reached edge cells in the first 64 words (and what it wants to keep in the next 64).  It starts from LDS alone --
+// nothing of the closure search stays in registers across it (movegen_closure_finish_mixed): the registers of this rare
+// path (a fifth of the T searches) must not weigh on the allocation of the kernels' ply loops.
+static __device__ __forceinline__ bool resolve_mixed_wave(CsScratch &C, int lane) {
+    const int rot = lane >> 4, mx = lane & 15;
+    uint64_t *reL = reinterpret_cast<uint64_t *>(&C.present[0][0]);                     // [64], 512 of the planes' 1056 bytes
+    const uint64_t valid = C.vcol[rot * 20 + mx + 2], re = reL[lane];
+    uint64_t mixed;
+    {
+        const uint64_t stuck = valid & ~(valid >> 1);
+        mixed = C.arr[1][rot * 20 + mx + 2] & C.arr[0][rot * 20 + mx + 2] & stuck;
+    }
+    // the first push into each of the states 1..3: the sources are the spawn region's edge cells, in (row, column, dir) order
+    uint32_t seed[3];                                                                    // key << 16 | target column << 8 | target row
+    {
+        const uint64_t src0 = (rot == 0) ? (C.snap[lane] & re) : 0ull;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            uint64_t kq = C.kick[d];
+            const int nk = (int)(kq >> 60);
+            uint64_t rem = src0;
+            uint32_t best = 0xFFFFFFFFu;
+#pragma unroll 1
+            for (int ki = 0; ki < 6; ki++, kq >>= 6) {
+                if (!__ballot(rem != 0 && ki < nk)) break;
+                const int fx = (int)(kq & 7), fy = (int)((kq >> 3) & 7);
+                const uint64_t vt = C.vcol[(d + 1) * 20 + mx + fx];
+                uint64_t fit = (vt << 2) >> (4 - fy);
+                if (ki >= nk) fit = 0;
+                uint64_t moved = rem & fit;
+                rem &= ~fit;
+                moved &= ~((1ull << fy) - 1ull);                                         // target row my - ky >= 2, else discarded (:462-463)
+                if (moved) {
+                    const int my = __ffsll((unsigned long long)moved) - 1;
+                    const uint32_t cand = ((uint32_t)((my << 6) | (mx << 2) | d) << 16) | ((uint32_t)(mx + fx - 2) << 8) | (uint32_t)(my - (fy - 2));
+                    best = cand < best ? cand : best;
+                }
+            }
+            seed[d] = wave_min_u32(best, lane);
+        }
+    }
+    // is every state's generation-1 region the flood of its first item?
+    {
+        uint64_t dm = 0;
+        if (rot > 0) {
+            const uint32_t sd = rot == 1 ? seed[0] : rot == 2 ? seed[1] : seed[2];
+            if (sd != 0xFFFFFFFFu && (int)((sd >> 8) & 0xFF) == mx) dm = 1ull << (sd & 0xFF);
+        }
+        for (;;) {
+            const uint64_t old = dm;
+            dm |= ((valid + dm) ^ valid) & valid;
+            dm |= (dpp64(dm, 0) | dpp64(dm, 1)) & valid;
+            if (!__ballot(dm != old)) break;
+        }
+        if (__ballot(rot > 0 && dm != C.snap[lane])) return false;
+    }
+    // cell by cell: the candidate sources (three other states x up to six kicks) one per lane
+    bool ok = true;
+    for (;;) {
+        const uint64_t have = __ballot(mixed != 0);
+        if (!have) break;
+        const int L = __ffsll((unsigned long long)have) - 1;
+        const int rK = L >> 4, xK = L & 15;
+        const uint32_t wlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mixed, L), whi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mixed >> 32), L);
+        const uint64_t word = (uint64_t)wlo | ((uint64_t)whi << 32);
+        const int yK = __ffsll((unsigned long long)word) - 1;
+        if (lane == L) mixed &= mixed - 1;
+        if (!((C.snap[L] >> yK) & 1)) { ok = false; break; }                              // the cell itself: generation <= 1 (0 in the spawn state)
+        uint64_t t = 0;                                                                  // (time << 1) | last kick, 0: no arrival
+        bool deep = false;
+        if (lane < 18) {
+            const int rs = (rK + 1 + lane / 6) & 3, ki = lane % 6;
+            const int d = (rK - rs - 1) & 3;
+            const uint64_t kq = C.kick[rs * 3 + d];
+            const int nk = (int)(kq >> 60);
+            if (ki < nk) {
+                const int fx = (int)((kq >> (6 * ki)) & 7), fy = (int)((kq >> (6 * ki + 3)) & 7);
+                const int sx = xK - (fx - 2), sy = yK + (fy - 2);
+                if (sx >= 0 && sx < MAP_W && sy >= 0 && sy < MAP_H && ((reL[rs * 16 + sx] >> sy) & 1)) {
+                    bool first = true;                                                   // no earlier kick of the list fits there
+                    for (int j = 0; j < ki; j++) {
+                        const int fx2 = (int)((kq >> (6 * j)) & 7), fy2 = (int)((kq >> (6 * j + 3)) & 7);
+                        const uint64_t vt = C.vcol[rK * 20 + sx + fx2];
+                        if ((((vt << 2) >> (4 - fy2)) >> sy) & 1) first = false;
+                    }
+                    if (first) {
+                        const uint64_t skey = (uint64_t)((sy << 6) | (sx << 2) | d);
+                        const uint64_t ulk = (d != 1 && ki == nk - 1) ? 1ull : 0ull;
+                        if (!((C.snap[rs * 16 + sx] >> sy) & 1)) deep = true;            // a source of a later generation
+                        else if (rs == 0) t = (((1ull << 40) | (skey << 21)) << 1) | ulk;
+                        else {
+                            const uint64_t ks = (rs == 1 ? seed[0] : rs == 2 ? seed[1] : seed[2]) >> 16;
+                            const uint64_t kK = rK == 0 ? 0ull : (rK == 1 ? seed[0] : rK == 2 ? seed[1] : seed[2]) >> 16;
+                            const bool visited = rK == 0 || kK < ks;
+                            t = ((visited ? ((1ull << 40) | (ks << 21) | (1ull << 20) | skey) : ((2ull << 40) | (ks << 21) | skey)) << 1) | ulk;
+                        }
+                    }
+                }
+            }
+        }
+        if (__ballot(deep)) { ok = false; break; }
+        const uint64_t win = wave_max_u64(t, lane);
+        if (lane == L) {
+            unsigned long long *w = reinterpret_cast<unsigned long long *>(&C.arr[(win & 1) ? 0 : 1][rK * 20 + xK + 2]);
+            *w &= ~(1ull << yK);                                                         // the losing class leaves the cell
+        }
+    }
+    wave_sync();
+    return ok;
+}
+
+// a 64-bit zero the compiler cannot keep: as an ordinary constant it is hoisted out of the kernels' ply loops as a register
+// pair, spilled there, and re-loaded from scratch memory for every guard word below
+__device__ __forceinline__ uint64_t fresh_zero64() {
+    uint32_t lo, hi;
+    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0" : "=v"(lo), "=v"(hi));
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// returns the number of placements, or -2: a T search with mixed cells (movegen_closure_finish_mixed goes on from here)
 static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows, int type, bool need_spawn, CsScratch &C,
                                                            uint16_t *out, int out_cap, int lane, int *overflow) {
     const int rot = lane >> 4, mx = lane & 15;
@@ -453,6 +611,7 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
         for (int i = lane; i < 2 * 4 * 20 * 2; i += 64) z[i] = 0;
         uint32_t *pz = reinterpret_cast<uint32_t *>(&C.present[0][0]);
         for (int i = lane; i < (isT ? 3 : 1) * 4 * MAP_H / 2; i += 64) pz[i] = 0;
+        if (isT) C.snap[lane] = fresh_zero64();
     }
     // _get_highest_row / _set_starting_position (move_generation.py:164-180)
     const uint64_t occm = __ballot(lane < TRL_ROWS && myrow != 0);
@@ -472,8 +631,8 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
         if (mx >= MAP_W) valid = 0;
     }
     C.vcol[rot * 20 + mx + 2] = valid;                      // (mx 14, 15: zeros at 16, 17)
-    if (mx < 2) C.vcol[rot * 20 + mx] = 0;                  // guards 0, 1
-    if (mx >= MAP_W) C.vcol[rot * 20 + mx + 4] = 0;         // guards 18, 19
+    if (mx < 2) C.vcol[rot * 20 + mx] = fresh_zero64();                  // guards 0, 1
+    if (mx >= MAP_W) C.vcol[rot * 20 + mx + 4] = fresh_zero64();         // guards 18, 19
     wave_sync();
     const uint64_t v0 = C.vcol[sx + 2 + 2];                 // rotation 0, column sx + 2
     bool ok = (v0 >> (sy + 2)) & 1;                                                      // :349-351
@@ -484,7 +643,7 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
     const uint64_t edge = valid & (~(valid >> 1) | ~dpp64(valid, 0) | ~dpp64(valid, 1));
     uint64_t reach = (lane == sx + 2) ? (1ull << (sy + 2)) : 0ull;
     uint64_t done = 0;
-    for (;;) {
+    for (int round = 0;; round++) {
         // fixed point under down / left / right inside every rotation state
         for (;;) {
             const uint64_t old = reach;
@@ -493,6 +652,8 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
             if (!__ballot(reach != old)) break;
         }
         if (!check_rot) break;
+        // T: the cells of generation 0 (the spawn region, rotation 0) and of generation <= 1 (resolve_mixed_wave)
+        if (isT && round < 2 && (round == 0) == (rot == 0)) C.snap[lane] = reach;
         // kicks of the edge cells that have not sent theirs yet (each cell sends once, like the flood that first visits it)
         const uint64_t src = reach & edge & ~done;
         done |= src;
@@ -529,7 +690,15 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
     const uint64_t stuck = valid & ~(valid >> 1);
     if (isT) {
         const uint64_t f1 = C.arr[1][rot * 20 + mx + 2] & stuck, f0 = C.arr[0][rot * 20 + mx + 2] & stuck;
-        if (__ballot((f1 & f0) != 0)) return -1;                                        // the walk's order decides: take it
+        if (__ballot((f1 & f0) != 0)) {
+            // the walk's order decides these cells: movegen_closure_finish_mixed settles them from the first two generations,
+            // or the walk is taken.  The planes' memory (zero so far) holds what that stage starts from
+            uint64_t *keep = reinterpret_cast<uint64_t *>(&C.present[0][0]);
+            keep[lane] = reach & edge;
+            keep[64 + lane] = reach & stuck;
+            wave_sync();
+            return -2;
+        }
         scatter_column(&C.flagp[0][0], f1 | f0, rot, mx);
         scatter_column(&C.ulp[0][0], f1, rot, mx);
     }
@@ -541,14 +710,42 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
     return total;
 }
 
+// second stage of a T search that stopped at mixed cells (movegen_closure_wave returned -2): settle them, then the planes and
+// the move list as in the first stage; -1: the ordered walk is needed
+static __device__ __forceinline__ int movegen_closure_finish_mixed(CsScratch &C, uint16_t *out, int out_cap, int lane, int *overflow) {
+    const int rot = lane >> 4, mx = lane & 15;
+    if (!uni(resolve_mixed_wave(C, lane))) return -1;
+    const uint64_t placed = reinterpret_cast<uint64_t *>(&C.present[0][0])[64 + lane];
+    const uint64_t valid = C.vcol[rot * 20 + mx + 2], stuck = valid & ~(valid >> 1);
+    const uint64_t f1 = C.arr[1][rot * 20 + mx + 2] & stuck, f0 = C.arr[0][rot * 20 + mx + 2] & stuck;
+    wave_sync();
+    uint32_t *pz = reinterpret_cast<uint32_t *>(&C.present[0][0]);
+    for (int i = lane; i < 3 * 4 * MAP_H / 2; i += 64) pz[i] = 0;
+    wave_sync();
+    scatter_column(&C.flagp[0][0], f1 | f0, rot, mx);
+    scatter_column(&C.ulp[0][0], f1, rot, mx);
+    scatter_column(&C.present[0][0], placed, rot, mx);
+    wave_sync();
+    int total = placements_to_moves(C, PT, out, out_cap, lane);
+    if (total > out_cap) { *overflow = 1; total = out_cap; }
+    wave_sync();
+    return total;
+}
+
 #ifndef TRL_CLOSURE
 #define TRL_CLOSURE 1       // 0: every search takes the ordered walk (A/B builds)
 #endif
 static __device__ __forceinline__ int movegen_wave(const uint16_t *rows, int type, bool need_spawn, MgScratch &S,
                                                    uint16_t *out, int out_cap, int lane, int *overflow) {
 #if TRL_CLOSURE
-    const int n = movegen_closure_wave(rows, type, need_spawn, reinterpret_cast<CsScratch &>(S), out, out_cap, lane, overflow);
+    int n = movegen_closure_wave(rows, type, need_spawn, reinterpret_cast<CsScratch &>(S), out, out_cap, lane, overflow);
     if (n >= 0) return n;
+#ifndef TRL_NO_RESOLVE_MIXED
+    if (n == -2) {
+        n = movegen_closure_finish_mixed(reinterpret_cast<CsScratch &>(S), out, out_cap, lane, overflow);
+        if (n >= 0) return n;
+    }
+#endif
 #endif
     return movegen_ordered_wave(rows, type, need_spawn, S, out, out_cap, lane, overflow);
 }

@@ -108,11 +108,55 @@ __device__ __forceinline__ uint16_t merged_move(const BfBlockShared &sh, int i) 
 }
 
 
+// ---- the search's per-slot control block (trl_mcts.hip), and the part of a tick that may run elsewhere -------------------
+struct SlotCtl {
+    int32_t phase;          // 0 = start a new search at the next select, 1 = searching, 2 = idle (game over, no auto-reset)
+    int32_t iter, max_iter, fast;
+    int32_t n_nodes, n_states;
+    int32_t leaf, leaf_kind, leaf_nlegal, leaf_state;
+    int32_t overflow, leaf_parent_state;      // state index of the leaf's parent (-1 at the root)
+    // what the selection knows and the expand would otherwise re-load through dependent global reads: the leaf's side to
+    // move, and its parent's node index and child range (FPU refresh of the siblings, ai.py:536-565)
+    int32_t leaf_turn, par_node, par_first, par_n;
+    int32_t depth, random_move;               // nodes on the selection path root .. leaf (DevMcts::path); this search picks a
+    double  terminal_value;                   // random starting move (ai.py:1588-1608)
+    double  rand_left;                        // num_random_moves still to play in this game
+};
+
+// The legal-move search of every slot's current leaf (get_move_matrix + get_move_list, ai.py:414-417) needs the leaf's
+// position only -- like the net's tower, and unlike everything after it in the tick.  Split off the selection it runs
+// either as k_leaf_legal on a second stream (trl_mcts_fork_legal) or as extra workgroups of the tower launch
+// (trl_mcts_tower16_legal, trl_net.hip): 64 VGPRs and 10 KB of LDS per workgroup, in the registers the tower's boards leave
+// free, and a T search that falls back to the ordered walk (3 % of the searches, 4 x the time) no longer sets the length
+// of the search kernel's launch.
+struct LeafLegalJob {
+    SlotCtl *ctl;                       // [n_slots]: phase, leaf_kind, leaf_state read; leaf_nlegal, overflow written
+    const trl_game_state *pool;         // [n_slots][cap_states]
+    uint16_t *leaf_moves;               // [n_slots][TRL_MAX_LEGAL]
+    unsigned long long *counters;       // [5] += 1 when a legal-move cap was hit
+    int cap_states, n_slots;
+};
+
+// all BLOCK (128) threads of a workgroup call it
+static __device__ __forceinline__ void leaf_legal_block(const LeafLegalJob &J, BlockShared &sh, int slot, int tid) {
+    const int phase = J.ctl[slot].phase, kind = J.ctl[slot].leaf_kind, sidx = J.ctl[slot].leaf_state;
+    if (phase != 1 || kind != 0) return;
+    load_state(sh, J.pool + (size_t)slot * J.cap_states + sidx, tid);
+    __syncthreads();
+    const int nlegal = block_movegen(sh, tid);
+    for (int i = tid; i < nlegal; i += BLOCK) J.leaf_moves[(size_t)slot * TRL_MAX_LEGAL + i] = merged_move(sh, i);
+    if (tid == 0) {
+        J.ctl[slot].leaf_nlegal = nlegal;
+        if (sh.overflow) { J.ctl[slot].overflow = 1; atomicAdd(&J.counters[5], 1ull); }
+    }
+}
+
 }  // namespace trl
 
 struct trl_mcts;   // search state (trl_mcts.hip)
 struct trl_engine;
 void trl_mcts_free_internal(trl_engine *h);   // trl_mcts.hip
+bool trl_mcts_leaf_legal_job(trl_engine *h, trl::LeafLegalJob *job);   // trl_mcts.hip: false unless trl_mcts_legal_in_tower is on
 
 struct trl_engine {
     trl_config cfg;

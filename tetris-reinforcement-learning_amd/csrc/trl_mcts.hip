@@ -28,19 +28,6 @@ constexpr int DEFAULT_MAX_NODES = 65536;
 constexpr int DEFAULT_REC_CAP = 16384;
 constexpr int HEAD_MAX_FEATS = 2048;          // widest policy-head input handled in the expand kernel (BaseResNet: 1653)
 
-struct SlotCtl {
-    int32_t phase;          // 0 = start a new search at the next select, 1 = searching, 2 = idle (game over, no auto-reset)
-    int32_t iter, max_iter, fast;
-    int32_t n_nodes, n_states;
-    int32_t leaf, leaf_kind, leaf_nlegal, leaf_state;
-    int32_t overflow, leaf_parent_state;      // state index of the leaf's parent (-1 at the root)
-    // what the selection knows and the expand would otherwise re-load through dependent global reads: the leaf's side to
-    // move, and its parent's node index and child range (FPU refresh of the siblings, ai.py:536-565)
-    int32_t leaf_turn, par_node, par_first, par_n;
-    int32_t depth, random_move;               // nodes on the selection path root .. leaf (DevMcts::path); this search picks a
-    double  terminal_value;                   // random starting move (ai.py:1588-1608)
-    double  rand_left;                        // num_random_moves still to play in this game
-};
 constexpr int PATH_CAP = 64;                  // deeper paths are backed up by walking the parent links
 
 struct Tree {               // device pointers, column per node field; slot s owns [s * max_nodes, (s + 1) * max_nodes)
@@ -368,17 +355,8 @@ __global__ __launch_bounds__(BLOCK) void k_select_bf(DevMcts M, trl_game_state *
 // 64 VGPRs and 10 KB of LDS per workgroup, so it runs in the registers the tower's two workgroups per CU leave free
 __global__ __launch_bounds__(BLOCK, 8) void k_leaf_legal(DevMcts M) {
     __shared__ BlockShared sh;
-    const int tid = threadIdx.x, slot = blockIdx.x;
-    const int phase = M.ctl[slot].phase, kind = M.ctl[slot].leaf_kind, sidx = M.ctl[slot].leaf_state;
-    if (phase != 1 || kind != 0) return;
-    load_state(sh, M.pool + (size_t)slot * M.cap_states + sidx, tid);
-    __syncthreads();
-    const int nlegal = block_movegen(sh, tid);
-    for (int i = tid; i < nlegal; i += BLOCK) M.leaf_moves[(size_t)slot * TRL_MAX_LEGAL + i] = merged_move(sh, i);
-    if (tid == 0) {
-        M.ctl[slot].leaf_nlegal = nlegal;
-        if (sh.overflow) { M.ctl[slot].overflow = 1; atomicAdd(&M.counters[5], 1ull); }
-    }
+    const LeafLegalJob J{M.ctl, M.pool, M.leaf_moves, M.counters, M.cap_states, M.n_games};
+    leaf_legal_block(J, sh, blockIdx.x, threadIdx.x);
 }
 
 // ---- tick part B --------------------------------------------------------------------------------------
@@ -862,6 +840,7 @@ constexpr int SEARCH_PRIO = TRL_SEARCH_PRIO;
 // `vec` is read by the expand (the leaf's feature vector) before the same workgroup's select overwrites it; `grids` were
 // consumed by the tower that ran before this launch.
 constexpr int FUSED_THREADS = 256;        // four waves for the expand half, the first two go on to the selection
+template <bool DO_LEGAL>      // false: the leaf's legal-move search runs in the tower launch that follows (LeafLegalJob)
 __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_expand_select(DevMcts M, trl_game_state *real, float *vec, const float *z,
                                                          const float *head_w, const float *head_b, HeadsDev H, float *grids,
                                                          uint8_t *need) {
@@ -874,7 +853,7 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(4
     if (threadIdx.x >= BLOCK) return;              // (slots that were not expanding: the extra waves end here)
     if (threadIdx.x == 0) carry = sh.e.ctl;        // as stored to M.ctl[slot] (or as loaded, for a slot that was not searching)
     __syncthreads();                               // the tree is in memory; the LDS block changes hands
-    select_body(sh.s, M, real, grids, vec, need, 1, &carry);
+    select_body(sh.s, M, real, grids, vec, need, DO_LEGAL ? 1 : 0, &carry);
 }
 
 // tower-output cache.  z: [2][n][400] as written by the tower for the boards flagged by k_select.  Afterwards
@@ -955,6 +934,8 @@ struct trl_mcts {
     int32_t *d_info_tmp;
     void *d_root_tmp;
     int fork_legal;                 // trl_mcts_fork_legal: the leaf's legal-move search runs on side_stream beside the tower
+    int legal_in_tower;             // trl_mcts_legal_in_tower: ... as extra workgroups of the tower launch (trl_mcts_tower16_legal)
+    bool legal_owed;                // a selection without its legal-move search has been queued: the tower launch must follow
     bool fork_pending;              // k_leaf_legal is in flight: the next expand joins it
     hipStream_t side_stream;
     hipEvent_t ev_fork, ev_join;
@@ -1052,6 +1033,7 @@ int trl_mcts_restart(trl_engine *h) {
     if (!h || !h->mcts) return fail(TRL_E_INVALID, "trl_mcts_restart: %s", "no search attached");
     HIPCHK(hipSetDevice(h->cfg.device));
     HIPCHK(hipMemsetAsync(h->mcts->d.ctl, 0, (size_t)h->cfg.n_games * sizeof(SlotCtl), h->stream));
+    h->mcts->legal_owed = false;                    // the pending selection is dropped with everything else
     return TRL_OK;
 }
 
@@ -1064,15 +1046,18 @@ int trl_mcts_select_need(trl_engine *h, float *dev_grids, float *dev_vec, uint8_
     HIPCHK(hipSetDevice(h->cfg.device));
     trl_mcts *m = h->mcts;
     const int fork = m->fork_legal && dev_need;         // only the tower-need flow has something to overlap with
+    const int in_tower = m->legal_in_tower && dev_need;
+    if (in_tower && m->legal_owed) return fail(TRL_E_STATE, "%s", "trl_mcts_legal_in_tower: a selection is waiting for trl_mcts_tower16_legal");
     if (m->d.cfg.move_algorithm == TRL_ALGO_BRUTE_FORCE) {
-        if (fork) return fail(TRL_E_STATE, "%s", "trl_mcts_fork_legal: not with move_algorithm = brute-force");
+        if (fork || in_tower) return fail(TRL_E_STATE, "%s", "trl_mcts_fork_legal / trl_mcts_legal_in_tower: not with move_algorithm = brute-force");
         hipLaunchKernelGGL(k_select_bf, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, m->d, h->d_states, dev_grids, dev_vec, dev_need);
         HIPCHK(hipGetLastError());
         return TRL_OK;
     }
     hipLaunchKernelGGL(k_select, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, m->d, h->d_states, dev_grids, dev_vec, dev_need,
-                       fork ? 0 : 1);
+                       (fork || in_tower) ? 0 : 1);
     HIPCHK(hipGetLastError());
+    if (in_tower) m->legal_owed = true;
     if (fork) {
         // fork: side_stream waits for k_select, runs k_leaf_legal; the next expand call joins (mcts_join).  Under stream
         // capture (trl_graph_begin) the two event waits become the graph's fork and join edges.
@@ -1104,7 +1089,19 @@ int trl_mcts_fork_legal(trl_engine *h, int on) {
         HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
     }
+    if (on && m->legal_in_tower) return fail(TRL_E_STATE, "%s", "trl_mcts_fork_legal: not with trl_mcts_legal_in_tower");
     m->fork_legal = on ? 1 : 0;
+    return TRL_OK;
+}
+
+int trl_mcts_legal_in_tower(trl_engine *h, int on) {
+    if (!h || !h->mcts) return fail(TRL_E_INVALID, "trl_mcts_legal_in_tower: %s", "no search attached");
+    trl_mcts *m = h->mcts;
+    if (on && m->fork_legal) return fail(TRL_E_STATE, "%s", "trl_mcts_legal_in_tower: not with trl_mcts_fork_legal");
+    if (on && m->d.cfg.move_algorithm != TRL_ALGO_CONVOLUTIONAL)
+        return fail(TRL_E_STATE, "%s", "trl_mcts_legal_in_tower: the tower launch runs the 'convolutional' generator only");
+    if (m->legal_owed) return fail(TRL_E_STATE, "%s", "trl_mcts_legal_in_tower: a selection is waiting for trl_mcts_tower16_legal");
+    m->legal_in_tower = on ? 1 : 0;
     return TRL_OK;
 }
 
@@ -1134,6 +1131,7 @@ int trl_mcts_expand(trl_engine *h, const float *dev_values, const float *dev_pol
     if (!h || !h->mcts || !dev_values || !dev_policy) return fail(TRL_E_INVALID, "trl_mcts_expand: %s", "null argument / no search attached");
     HIPCHK(hipSetDevice(h->cfg.device));
     { int rcj = mcts_join(h); if (rcj != TRL_OK) return rcj; }
+    if (h->mcts->legal_owed) return fail(TRL_E_STATE, "%s", "trl_mcts_legal_in_tower: the expand needs the leaf's legal moves -- trl_mcts_tower16_legal first");
     hipLaunchKernelGGL(k_expand<0>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_values,
                        dev_policy, (const float *)nullptr, (const float *)nullptr, 0, HeadsDev{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0});
     HIPCHK(hipGetLastError());
@@ -1147,6 +1145,7 @@ int trl_mcts_expand_head(trl_engine *h, const float *dev_values, const float *de
         return fail(TRL_E_INVALID, "trl_mcts_expand_head: %s", "bad argument / no search attached");
     HIPCHK(hipSetDevice(h->cfg.device));
     { int rcj = mcts_join(h); if (rcj != TRL_OK) return rcj; }
+    if (h->mcts->legal_owed) return fail(TRL_E_STATE, "%s", "trl_mcts_legal_in_tower: the expand needs the leaf's legal moves -- trl_mcts_tower16_legal first");
     hipLaunchKernelGGL(k_expand<1>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_values,
                        dev_feats, dev_head_weight, dev_head_bias, feat_dim, HeadsDev{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, nullptr, 0});
     HIPCHK(hipGetLastError());
@@ -1163,6 +1162,7 @@ int trl_mcts_expand_alphasame_masked(trl_engine *h, const float *dev_z, const fl
     if (h->mcts->d.zdim != 400) return fail(TRL_E_STATE, "%s", "trl_mcts_expand_alphasame needs the 400-float tower cache (trl_mcts_zcache_dim)");
     HeadsDev H{w->oside_w, w->oside_b, w->value0_w, w->value0_b, w->value3_w, w->value3_b, w->use_tanh, dev_slot_mask, want};
     { int rcj = mcts_join(h); if (rcj != TRL_OK) return rcj; }
+    if (h->mcts->legal_owed) return fail(TRL_E_STATE, "%s", "trl_mcts_legal_in_tower: the expand needs the leaf's legal moves -- trl_mcts_tower16_legal first");
     hipLaunchKernelGGL(k_expand<2>, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->mcts->d, h->d_states, dev_vec,
                        dev_z, w->policy_w, w->policy_b, 521, H);
     HIPCHK(hipGetLastError());
@@ -1185,8 +1185,14 @@ int trl_mcts_expand_alphasame_select(trl_engine *h, const float *dev_z, float *d
     if (h->mcts->d.cfg.move_algorithm != TRL_ALGO_CONVOLUTIONAL)
         return fail(TRL_E_STATE, "%s", "trl_mcts_expand_alphasame_select: the fused launch runs the 'convolutional' generator only");
     HeadsDev H{w->oside_w, w->oside_b, w->value0_w, w->value0_b, w->value3_w, w->value3_b, w->use_tanh, nullptr, 0};
-    hipLaunchKernelGGL(k_expand_select, dim3(h->cfg.n_games), dim3(FUSED_THREADS), 0, h->stream, h->mcts->d, h->d_states, dev_vec,
-                       dev_z, w->policy_w, w->policy_b, H, dev_grids, dev_need);
+    if (h->mcts->legal_owed) return fail(TRL_E_STATE, "%s", "trl_mcts_legal_in_tower: the expand needs the leaf's legal moves -- trl_mcts_tower16_legal first");
+    if (h->mcts->legal_in_tower && dev_need) {
+        hipLaunchKernelGGL(k_expand_select<false>, dim3(h->cfg.n_games), dim3(FUSED_THREADS), 0, h->stream, h->mcts->d, h->d_states, dev_vec,
+                           dev_z, w->policy_w, w->policy_b, H, dev_grids, dev_need);
+        h->mcts->legal_owed = true;
+    } else
+        hipLaunchKernelGGL(k_expand_select<true>, dim3(h->cfg.n_games), dim3(FUSED_THREADS), 0, h->stream, h->mcts->d, h->d_states, dev_vec,
+                           dev_z, w->policy_w, w->policy_b, H, dev_grids, dev_need);
     HIPCHK(hipGetLastError());
     h->mcts->ticks++;
     return TRL_OK;
@@ -1220,6 +1226,54 @@ int trl_mcts_drain_records_dev(trl_engine *h, trl_record *dev_out, int cap, int 
     if (cnt) HIPCHK(hipMemcpyAsync(dev_out, d.recs, (size_t)cnt * sizeof(trl_record), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipMemsetAsync(d.rec_count, 0, 4, h->stream));
     *n_out = (int)cnt;
+    return TRL_OK;
+}
+
+// ---- records out without a host round trip ---------------------------------------------------------------------------
+// trl_mcts_drain_records_dev reads the pending count on the host: the stream drains, and a job ticking in chunks idles for
+// the host's turnaround at every chunk.  Here the count stays on the device: one launch appends the pending records to
+// the caller's buffer behind the ones already there, a second one (same stream, so after every block of the first has
+// read the counts) advances the caller's count, snapshots the search counters next to it and clears the pending count.
+__global__ void __launch_bounds__(256) k_drain_copy(const trl_record *src, const unsigned int *rec_count, int rec_cap,
+                                                    trl_record *dst, const unsigned long long *head, int dst_cap, unsigned int slot_offset) {
+    unsigned int cnt = *rec_count;
+    if (cnt > (unsigned)rec_cap) cnt = (unsigned)rec_cap;
+    unsigned long long base = head[0];
+    unsigned long long room = base < (unsigned long long)dst_cap ? (unsigned long long)dst_cap - base : 0ull;
+    if (cnt > room) cnt = (unsigned int)room;
+    constexpr unsigned int W = sizeof(trl_record) / 8;               // 299 eight-byte words per record
+    static_assert(sizeof(trl_record) % 8 == 0, "records are copied in 8-byte words");
+    const unsigned long long *s = reinterpret_cast<const unsigned long long *>(src);
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(dst + base);
+    size_t total = (size_t)cnt * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long v = s[i];
+        if (i % W == 0) v = (v & 0xffffffff00000000ull) | (unsigned long long)((unsigned int)v + slot_offset);   // word 0 = slot | episode << 32
+        d[i] = v;
+    }
+}
+
+__global__ void k_drain_commit(unsigned int *rec_count, int rec_cap, unsigned long long *head, int dst_cap, unsigned long long *counters) {
+    unsigned int cnt = *rec_count;
+    if (cnt > (unsigned)rec_cap) cnt = (unsigned)rec_cap;
+    unsigned long long base = head[0];
+    unsigned long long room = base < (unsigned long long)dst_cap ? (unsigned long long)dst_cap - base : 0ull;
+    unsigned int n = cnt > room ? (unsigned int)room : cnt;
+    if (n < cnt) counters[3] += cnt - n;                              // records_dropped: the caller's buffer was full
+    head[0] = base + n;
+    for (int k = 0; k < 8; ++k) head[1 + k] = counters[k];
+    *rec_count = 0;
+}
+
+int trl_mcts_drain_records_async(trl_engine *h, trl_record *dev_out, int cap, uint64_t *dev_head, uint32_t slot_offset) {
+    if (!h || !h->mcts || !dev_out || !dev_head || cap < 0) return fail(TRL_E_INVALID, "trl_mcts_drain_records_async: %s", "bad argument");
+    if (((uintptr_t)dev_out & 7) || ((uintptr_t)dev_head & 7)) return fail(TRL_E_INVALID, "trl_mcts_drain_records_async: %s", "buffers must be 8-byte aligned");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    DevMcts &d = h->mcts->d;
+    hipLaunchKernelGGL(k_drain_copy, dim3(256), dim3(256), 0, h->stream, d.recs, d.rec_count, d.rec_cap, dev_out,
+                       (const unsigned long long *)dev_head, cap, slot_offset);
+    hipLaunchKernelGGL(k_drain_commit, dim3(1), dim3(1), 0, h->stream, d.rec_count, d.rec_cap, (unsigned long long *)dev_head, cap, d.counters);
+    HIPCHK(hipGetLastError());
     return TRL_OK;
 }
 
@@ -1293,3 +1347,14 @@ int trl_debug_stub_eval_salted(trl_engine *h, float *dev_values, float *dev_poli
 }
 
 }  // extern "C"
+
+// trl_net.hip asks for the job when it launches the tower: true (and the job filled in) when a selection of this engine
+// left its legal-move search to the tower launch
+bool trl_mcts_leaf_legal_job(trl_engine *h, LeafLegalJob *job) {
+    if (!h || !h->mcts || !h->mcts->legal_in_tower) return false;
+    DevMcts &d = h->mcts->d;
+    *job = LeafLegalJob{d.ctl, d.pool, d.leaf_moves, d.counters, d.cap_states, d.n_games};
+    h->mcts->legal_owed = false;
+    return true;
+}
+

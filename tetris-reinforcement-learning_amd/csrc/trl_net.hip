@@ -21,7 +21,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "trl_internal.h"
+using namespace trl;
 
 namespace {
 
@@ -424,11 +426,25 @@ __device__ __forceinline__ void conv3x3s(const SBase (&sb)[7], int d1, int d10, 
     for (int s = 0; s < 7; s++) am[s] *= INV_SPLIT;
 }
 
-template <int MINB, bool ILV>
+// LEGAL: the first job.n_slots workgroups of the launch run the search's legal-move job instead of a board
+// (leaf_legal_block, trl_internal.h: two of their four waves, the others end at once); board b is workgroup n_slots + b
+struct NoLegalJob {};
+template <int MINB, bool ILV, bool LEGAL = false>
 __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *__restrict__ boards, const float *__restrict__ wts,
                                                                   int n_blocks, float *__restrict__ out,
-                                                                  const uint8_t *__restrict__ need) {
-    if (need && !need[blockIdx.x]) return;
+                                                                  const uint8_t *__restrict__ need,
+                                                                  std::conditional_t<LEGAL, LeafLegalJob, NoLegalJob> job = {}) {
+    int block_id = blockIdx.x;
+    if constexpr (LEGAL) {
+        if (block_id < job.n_slots) {
+            if (threadIdx.x >= BLOCK) return;
+            __shared__ BlockShared lsh;
+            leaf_legal_block(job, lsh, block_id, threadIdx.x);
+            return;
+        }
+        block_id -= job.n_slots;
+    }
+    if (need && !need[block_id]) return;
     TPROF_T(tp_start);
     __builtin_amdgcn_s_setprio(3);
     __shared__ __attribute__((aligned(16))) float lds[HPLANE + BW * BH + 4 * 256];
@@ -436,7 +452,7 @@ __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *_
     float *brd = lds + HPLANE, *part = lds + HPLANE + BW * BH;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, pn = lane & 15;      // result layout: channels 4 g + r of tile position pn
-    const size_t board = blockIdx.x;
+    const size_t board = (size_t)block_id;
 
     for (int i = tid; i < (HPLANE + BW * BH + 4 * 256) / 4; i += TRUNK_THREADS)
         reinterpret_cast<f32x4 *>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1178,6 +1194,27 @@ int trl_alphasame_trunk16_split(const float *dev_boards, int n_boards, const flo
     else
         hipLaunchKernelGGL((k_trunk16s<2, false>), dim3(n_boards), dim3(TRUNK_THREADS), 0, (hipStream_t)stream, dev_boards,
                            dev_packed, n_blocks, dev_out, dev_need);
+    HIPCHK(hipGetLastError());
+    return TRL_OK;
+}
+
+// The split 16-filter tower of one search tick together with the search's legal-move job (trl_mcts_legal_in_tower): the
+// boards are the grids trl_mcts_select_need / trl_mcts_expand_alphasame_select wrote, dev_need their flags; runs on the
+// engine's stream.
+int trl_mcts_tower16_legal(trl_engine *h, const float *dev_boards, int n_boards, const float *dev_packed, int n_blocks,
+                           float *dev_out, const uint8_t *dev_need) {
+    if (!h || !dev_boards || !dev_packed || !dev_out || !dev_need || n_boards <= 0 || n_blocks < 0)
+        return fail(TRL_E_INVALID, "trl_mcts_tower16_legal: %s", "bad argument");
+    LeafLegalJob job;
+    if (!trl_mcts_leaf_legal_job(h, &job)) return fail(TRL_E_STATE, "trl_mcts_tower16_legal: %s", "trl_mcts_legal_in_tower is not on");
+    HIPCHK(hipSetDevice(h->cfg.device));
+    static const int force = getenv("TRL_SPLIT_ILV") ? atoi(getenv("TRL_SPLIT_ILV")) : -1;
+    if (force < 0 ? n_boards <= 1024 : force != 0)
+        hipLaunchKernelGGL((k_trunk16s<2, true, true>), dim3(job.n_slots + n_boards), dim3(TRUNK_THREADS), 0, h->stream, dev_boards,
+                           dev_packed, n_blocks, dev_out, dev_need, job);
+    else
+        hipLaunchKernelGGL((k_trunk16s<2, false, true>), dim3(job.n_slots + n_boards), dim3(TRUNK_THREADS), 0, h->stream, dev_boards,
+                           dev_packed, n_blocks, dev_out, dev_need, job);
     HIPCHK(hipGetLastError());
     return TRL_OK;
 }

@@ -22,10 +22,10 @@ ABI_SYMBOLS = [
     "trl_env_reset", "trl_env_get_state", "trl_env_set_state", "trl_env_state_dev",
     "trl_env_legal_moves", "trl_env_legal_moves_algo", "trl_env_legal_dev", "trl_env_step", "trl_env_step_dev",
     "trl_env_rollout_random", "trl_last_kernel_ms",
-    "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_expand_head", "trl_mcts_drain_records", "trl_mcts_drain_records_dev", "trl_mcts_get_stats",
+    "trl_mcts_create", "trl_mcts_select", "trl_mcts_expand", "trl_mcts_expand_head", "trl_mcts_drain_records", "trl_mcts_drain_records_dev", "trl_mcts_drain_records_async", "trl_mcts_get_stats",
     "trl_mcts_leaf_states", "trl_mcts_root_children", "trl_alphasame_trunk16", "trl_alphasame_trunk16_need", "trl_alphasame_trunk16_split", "trl_trunk_wide_split", "trl_alphasame_trunk", "trl_resnet_trunk", "trl_graph_begin", "trl_graph_end", "trl_graph_end_many", "trl_graph_launch",
     "trl_tower_overflow",
-    "trl_mcts_select_need", "trl_mcts_fork_legal", "trl_mcts_expand_alphasame_masked", "trl_mcts_zcache", "trl_mcts_zcache_dim", "trl_mcts_expand_alphasame", "trl_mcts_expand_alphasame_select", "trl_mcts_restart",
+    "trl_mcts_select_need", "trl_mcts_fork_legal", "trl_mcts_expand_alphasame_masked", "trl_mcts_zcache", "trl_mcts_zcache_dim", "trl_mcts_expand_alphasame", "trl_mcts_expand_alphasame_select", "trl_mcts_restart", "trl_mcts_legal_in_tower", "trl_mcts_tower16_legal",
 ]
 
 GRID_FLOATS = 400
@@ -129,6 +129,7 @@ def load_library(path=None):
     L.trl_mcts_expand_head.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.trl_mcts_drain_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
     L.trl_mcts_drain_records_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    L.trl_mcts_drain_records_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32]
     L.trl_mcts_get_stats.argtypes = [C.c_void_p, C.POINTER(TrlMctsStats)]
     L.trl_mcts_leaf_states.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.trl_mcts_root_children.argtypes = [C.c_void_p] + [C.c_void_p] * 5
@@ -142,6 +143,8 @@ def load_library(path=None):
     L.trl_graph_launch.argtypes = [C.c_void_p, C.c_int]
     L.trl_mcts_expand_alphasame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(TrlAlphaSameHeads)]
     L.trl_mcts_restart.argtypes = [C.c_void_p]
+    L.trl_mcts_legal_in_tower.argtypes = [C.c_void_p, C.c_int]
+    L.trl_mcts_tower16_legal.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.trl_mcts_expand_alphasame_select.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(TrlAlphaSameHeads), C.c_void_p, C.c_void_p]
     L.trl_mcts_expand_alphasame_masked.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(TrlAlphaSameHeads),
                                                    C.c_void_p, C.c_int, C.c_int]
@@ -310,6 +313,15 @@ class Engine:
     def mcts_expand_alphasame(self, z_ptr, vec_ptr, heads):
         _check(self._L, self._L.trl_mcts_expand_alphasame(self._h, z_ptr, vec_ptr, C.byref(heads)), "trl_mcts_expand_alphasame")
 
+    def mcts_legal_in_tower(self, on=True):
+        """the leaf's legal-move search as extra workgroups of the tower launch (trl_mcts_tower16_legal) instead of the
+        selection's"""
+        _check(self._L, self._L.trl_mcts_legal_in_tower(self._h, 1 if on else 0), "trl_mcts_legal_in_tower")
+
+    def mcts_tower16_legal(self, boards_ptr, n_boards, packed_ptr, n_blocks, out_ptr, need_ptr):
+        _check(self._L, self._L.trl_mcts_tower16_legal(self._h, boards_ptr, int(n_boards), packed_ptr, int(n_blocks), out_ptr, need_ptr),
+               "trl_mcts_tower16_legal")
+
     def mcts_restart(self):
         _check(self._L, self._L.trl_mcts_restart(self._h), "trl_mcts_restart")
 
@@ -340,6 +352,13 @@ class Engine:
         n = C.c_int(0)
         _check(self._L, self._L.trl_mcts_drain_records_dev(self._h, dev_ptr, int(cap), C.byref(n)), "trl_mcts_drain_records_dev")
         return n.value
+
+    def mcts_drain_records_async(self, dev_ptr, cap, head_ptr, slot_offset=0):
+        """pending records appended to the device buffer at dev_ptr (room for `cap` records in all) behind the head_ptr[0]
+        records already there; head_ptr: uint64[9] on the device ([0] count, [1..8] search counters at this drain).
+        Queued on the engine's stream; nothing is waited for."""
+        _check(self._L, self._L.trl_mcts_drain_records_async(self._h, dev_ptr, int(cap), head_ptr, int(slot_offset)),
+               "trl_mcts_drain_records_async")
 
     def mcts_stats(self):
         st = TrlMctsStats()

@@ -334,6 +334,23 @@ class AlphaSame(nn.Module):
         fd = self._folded or self.prepare()._folded
         return self._trunk_hip(grids.reshape(-1, 1, ROWS, COLS), fd["packed_tower"], need, out)
 
+    @property
+    def supports_tower_legal(self):
+        """True when the tick's tower launch can carry the search's legal-move job (trl_mcts_tower16_legal): the split
+        16-filter tower"""
+        fd = self._folded or self.prepare()._folded
+        return bool(self.tower_mode == "split" and fd.get("packed_split") is not None and self.model_config.filters == 16
+                    and self.use_hip_trunk)
+
+    def tower_legal(self, engine, grids, need, out):
+        """tower_need(grids, need, out) on the engine's stream with the legal-move search of the engine's pending leaves
+        in the same launch (Engine.mcts_legal_in_tower)"""
+        fd = self._folded or self.prepare()._folded
+        m = grids.shape[0] * grids.shape[1]
+        engine.mcts_tower16_legal(grids.data_ptr(), m, fd["packed_split"].data_ptr(), len(self.res_blocks), out.data_ptr(),
+                                  need.data_ptr())
+        return out
+
     @torch.no_grad()
     def head_inputs(self, grids, vec, z=None):
         """-> (value [n] before the output activation, x [n, 521] = input of the policy head);

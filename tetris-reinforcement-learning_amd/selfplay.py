@@ -121,6 +121,9 @@ def derive_seed(base, *parts):
 
 # ---- the tick loop ----------------------------------------------------------------------------------------
 FUSE_SELECT = os.environ.get("TRL_FUSE_SELECT", "1") != "0"   # native tick: expand + next select as one launch
+DRAIN_HEAD_WORDS = 9            # trl_mcts_drain_records_async's dev_head: [0] records, [1..8] search counters at that drain
+DRAIN_HEAD_FIELDS = ("simulations", "moves", "games", "records_dropped", "max_nodes_used", "overflow", "ticks")
+LEGAL_IN_TOWER = os.environ.get("TRL_LEGAL_IN_TOWER", "1") != "0"   # the fused tick's legal-move search in its tower launch
 GRAPH_TICKS = int(os.environ.get("TRL_GRAPH_TICKS", "8"))      # ticks per launch of the long tick graph (1: single-tick graph only)
 
 
@@ -151,6 +154,7 @@ class SelfPlay:
                                                record_capacity=record_capacity, episodes_base=int(episodes[0]),
                                                episodes_extra=int(episodes[1])))
         self._rec_dev = None
+        self._acc = None
         with torch.cuda.stream(self.stream):
             self.grids = torch.zeros((2, self.n, _eng.GRID_FLOATS), dtype=torch.float32, device=self.device)
             self.vec = torch.zeros((self.n, _eng.VEC_FLOATS), dtype=torch.float32, device=self.device)
@@ -175,6 +179,7 @@ class SelfPlay:
         self.graph_many = None
         self.native_graph = False
         self.fused_select = False
+        self.legal_in_tower = False
         self.ticks = 0
         if use_graph:
             self._capture()
@@ -184,7 +189,7 @@ class SelfPlay:
         # v / p / x / z live in the stream-ordered allocator (a fixed address inside a captured graph)
         if self.fused_select:
             # the selection of this simulation was made by the previous tick's launch (or by _capture for the first one)
-            self.net.tower_need(self.grids, self.need, out=self.z)
+            self._tower()
             e.mcts_expand_alphasame_select(self.z.data_ptr(), self.vec.data_ptr(), self.heads, self.grids.data_ptr(), self.need.data_ptr())
             return
         if self.tower_cache:
@@ -210,6 +215,14 @@ class SelfPlay:
             ph = self.net.policy_head
             e.mcts_expand_head(v.data_ptr(), x.data_ptr(), x.shape[1], ph.weight.data_ptr(), ph.bias.data_ptr())
 
+    def _tower(self):
+        """the tower launch of the fused tick: the boards the pending selection flagged -- and, with legal_in_tower, the
+        legal-move search of its leaves in the same launch"""
+        if self.legal_in_tower:
+            self.net.tower_legal(self.engine, self.grids, self.need, out=self.z)
+        else:
+            self.net.tower_need(self.grids, self.need, out=self.z)
+
     def _capture(self):
         torch = self.torch
         if self.tower_cache and self.heads is not None:
@@ -219,6 +232,11 @@ class SelfPlay:
                 if FUSE_SELECT and not self.fork_legal and self.config.move_algorithm == "convolutional":
                     # expand of one simulation and select of the next in one launch (trl_mcts_expand_alphasame_select):
                     # the first selection is made here, every tick after it is {tower, expand + select}
+                    if LEGAL_IN_TOWER and getattr(self.net, "supports_tower_legal", False) and self.grids.is_contiguous():
+                        # the leaf's legal-move search rides in the tower launch (trl_mcts_legal_in_tower): it needs the
+                        # leaf's position only, and its slow cases then overlap the tower instead of ending the search launch
+                        self.engine.mcts_legal_in_tower(True)
+                        self.legal_in_tower = True
                     self.engine.mcts_select_need(self.grids.data_ptr(), self.vec.data_ptr(), self.need.data_ptr())
                     self.fused_select, self._select_epoch = True, self.engine.state_epoch
                 self.engine.graph_begin()
@@ -296,6 +314,46 @@ class SelfPlay:
         # the clone was enqueued on this object's stream; its readers (torch.cat, the RCCL gather) run on theirs
         done.synchronize()
         return out
+
+    def drain_async(self, slot_offset=0):
+        """Queue "pending records -> one of two accumulators in HBM" behind the ticks queued so far and return a ticket;
+        nothing is waited for, so the next chunk of ticks can be queued right behind it (trl_mcts_drain_records_async).
+        take(ticket) hands the records over.  Two accumulators: a ticket must be taken before the next but one is drawn."""
+        torch = self.torch
+        cap = self.engine._rec_cap
+        if self._acc is None:
+            with torch.cuda.stream(self.stream):
+                self._acc = [(torch.empty(cap * _eng.RECORD_DTYPE.itemsize, dtype=torch.uint8, device=self.device),
+                              torch.zeros(DRAIN_HEAD_WORDS, dtype=torch.int64, device=self.device)) for _ in range(2)]
+            self._acc_busy = [False, False]
+            self._acc_next = 0
+            self._side = torch.cuda.Stream(device=self.device)
+        i = self._acc_next
+        if self._acc_busy[i]:
+            raise RuntimeError("drain_async: take() the ticket drawn two drains ago first")
+        buf, head = self._acc[i]
+        self.engine.mcts_drain_records_async(buf.data_ptr(), cap, head.data_ptr(), slot_offset)
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        self._acc_busy[i] = True
+        self._acc_next = i ^ 1
+        return i, done
+
+    def take(self, ticket):
+        """(records of a drain_async ticket as a uint8 tensor in HBM, the search counters as of that drain).  Waits for
+        that drain only -- on a side stream, so neither the wait nor the copies queue behind ticks enqueued since."""
+        torch = self.torch
+        i, done = ticket
+        buf, head = self._acc[i]
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(done)
+            h = head.cpu()                                   # (synchronises the side stream)
+            n = int(h[0])
+            out = buf[:n * _eng.RECORD_DTYPE.itemsize].clone()
+            head.zero_()
+        self._side.synchronize()
+        self._acc_busy[i] = False
+        return out, {k: int(h[1 + j]) for j, k in enumerate(DRAIN_HEAD_FIELDS)}
 
     def stats(self):
         """trl_mcts_stats + "tower_overflow": boards (since the last call, on this device) whose activations left the f16
@@ -407,6 +465,21 @@ class SelfPlayGroups:
         res = torch.cat(out) if len(out) > 1 else out[0]                              # (current stream: the copies are complete)
         torch.cuda.current_stream(self.device).synchronize()
         return res
+
+    def drain_async(self, slot_offset=0):
+        """every group's SelfPlay.drain_async (the records carry global slot numbers when they arrive); one ticket"""
+        return [p.drain_async(slot_offset + g * self.m) for g, p in enumerate(self.parts)]
+
+    def take(self, ticket):
+        got = [p.take(t) for p, t in zip(self.parts, ticket)]
+        torch = self.torch
+        recs = torch.cat([r for r, _ in got]) if len(got) > 1 else got[0][0]
+        torch.cuda.current_stream(self.device).synchronize()
+        sts = [st for _, st in got]
+        out = {k: sum(st[k] for st in sts) for k in sts[0]}
+        out["ticks"] = sts[0]["ticks"]
+        out["max_nodes_used"] = max(st["max_nodes_used"] for st in sts)
+        return recs, out
 
     def stats(self):
         sts = [p.stats() for p in self.parts]
@@ -552,39 +625,62 @@ def _play_collect(config, network, num_games, seed, device=0, max_slots=1024, st
     cdev = sp.device if nccl else None
     rec_bytes = _eng.RECORD_DTYPE.itemsize
     chunk = _chunk_ticks(config, slots)
+    tower_split = getattr(network, "tower_mode", "") == "split"
+    dev_index = sp.device.index or 0
+
+    def as_records(t):
+        return np.frombuffer(t.cpu().numpy().tobytes(), dtype=_eng.RECORD_DTYPE).copy()
+
+    # Two chunks are in flight: the next chunk of ticks (and the drain behind it) is queued BEFORE the host waits for the
+    # previous drain, so the device never idles for the host's turnaround; records and the counters that say "done" come
+    # out of SelfPlay.take() on a side stream.  The price: one chunk of ticks is queued after the last game has ended
+    # (every slot has stopped by then: its quota is played / auto_reset is off -- the ticks find nothing to do).
     sp.tick(chunk)
+    pending, local_done, st = sp.drain_async(), False, None
     while True:
-        if nccl:
-            mine = sp.drain_dev()                              # stays in HBM
-        else:
-            r = sp.drain()
-        st = sp.stats()
+        nxt = None
+        if not local_done:
+            sp.tick(chunk)
+            nxt = sp.drain_async()
+        mine, st = sp.take(pending)                            # stays in HBM
+        st["tower_overflow"] = _eng.tower_overflow(dev_index, reset=True) if tower_split else 0
         bad = int(bool(st["records_dropped"] or st["overflow"] or st["tower_overflow"]))
         local_done = st["games"] >= num_games
         if multi:
             if not nccl:
-                mine = sp.torch.from_numpy(r.view(np.uint8).reshape(-1))
+                mine = mine.cpu()
             info = parallel.all_gather_ints([mine.numel(), int(local_done), bad], dist, cdev)
             bad, all_done = int(info[:, 2].any()), bool(info[:, 1].all())
         else:
             all_done = local_done
         if bad:                                                # every rank leaves the loop together
+            sp.synchronize()                                   # (the chunk queued ahead runs out first: nothing of this job
+            if tower_split:                                    # is left on the device, nor in the range guard's counter)
+                _eng.tower_overflow(dev_index, reset=True)
             raise _eng.EngineError("device record buffer or tree capacity overflowed, or (tower_overflow) an activation left "
                                    "the f16 range of the split tower kernels -- set network.tower_mode = 'fp32': %r" % (st,))
-        if not local_done:
-            sp.tick(chunk)                                     # the device goes on while the records travel / are converted
         if multi:
             parts = parallel.gather_tensor(mine, info[:, 0], dist) if info[:, 0].any() else None
             if rank == 0 and parts is not None:
                 for rk, part in enumerate(parts):
                     if part.numel():
-                        rr = np.frombuffer(part.cpu().numpy().tobytes(), dtype=_eng.RECORD_DTYPE).copy()
+                        rr = as_records(part)
                         rr["slot"] += np.uint32(rk * slots)
                         col.add(rr[np.lexsort((rr["kind"], rr["ply"], rr["slot"], rr["episode"]))])
         else:
+            r = as_records(mine)
             col.add(r[np.lexsort((r["kind"], r["ply"], r["slot"], r["episode"]))])
+        if nxt is None:
+            # this rank was done a round ago and has nothing queued; while other ranks still play it takes part in the
+            # exchanges with an empty contribution
+            pending = sp.drain_async()
+        else:
+            pending = nxt
         if all_done:
             break
+    late, st = sp.take(pending)                                # queued after the last game ended: must be empty
+    if late.numel():
+        raise _eng.EngineError("%d bytes of records after the last game of the set" % late.numel())
     if rank != 0:
         return []
     games = col.finished
