@@ -195,8 +195,9 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
                         "before_timed_region": {"tower_ms": round(tk0[0], 4), "k_expand_select_ms": round(tk0[1], 4)},
                         "after_timed_region": {"tower_ms": round(tk1[0], 4), "k_expand_select_ms": round(tk1[1], 4)},
                         "how": "HIP events on one slot group's stream round its two launches, 32 eager ticks (medians; the first 8 not counted) before and 32 "
-                               "after the timed region, the other groups idle; the figure is the mean of the two -- what the kernel "
-                               "trace's per-grid average of the same run shows (profiles/: kernel_trace_by_grid)"}
+                               "after the timed region, the other groups idle, the cost of recording an event (measured in the same "
+                               "loop) taken off; the figure is the mean of the two -- what the kernel trace's per-grid average of "
+                               "the same run shows (profiles/: kernel_trace_by_grid)"}
         pm = load_pmc("r03_mcts_pmc.json")
         search_bytes = SIM_BYTES * slots
         gbs = search_bytes / (search_ms * 1e-3) / 1e9
@@ -204,8 +205,9 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
                         "frac": round(gbs / HBM_PEAK_GBS, 6), "traffic": None, "kernel": "k_expand_select",
                         "kernel_ms": round(search_ms, 4), "simulations_per_launch": slots,
                         "algorithmic_bytes_per_simulation": SIM_BYTES, "survey_bytes_per_simulation": SIM_BYTES_SURVEY,
-                        "note": "one workgroup per slot walking a dependent chain (selection, make_move, legal-move search, heads, "
-                                "backup): latency-bound, neither HBM nor issue binds; the HBM fraction is nominal (SURVEY 8d). "
+                        "note": "one workgroup per slot walking a dependent chain (heads, expansion, backup, selection, make_move; "
+                                "the leaf's legal-move search rides in the tower launch): latency-bound, neither HBM nor issue "
+                                "binds; the HBM fraction is nominal (SURVEY 8d). "
                                 "Algorithmic bytes: DESIGN.md 3.3 (the 46 KB policy row of SURVEY's 54 KB is fused away)"}
         if pm and pm.get("kernel") == "k_expand_select":
             scale = slots / float(pm["slots_per_launch"])
@@ -522,19 +524,24 @@ def time_tick_kernels(sp, reps=48):
     torch = part.torch
     for p in getattr(sp, "parts", [sp]):
         p.synchronize()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(reps)]
+    # four events per tick: e0 | tower | e1 e1b | search | e2 -- the interval e1 -> e1b holds nothing but the recording of
+    # an event (3-4 us), which every other interval contains once as well and which is taken off (without it the shorter
+    # kernel read 14 % long against the kernel trace)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(reps)]
     with torch.cuda.stream(part.stream):
-        for e0, e1, e2 in ev:
+        for e0, e1, e1b, e2 in ev:
             e0.record(part.stream)
             part._tower()
             e1.record(part.stream)
+            e1b.record(part.stream)
             part.engine.mcts_expand_alphasame_select(part.z.data_ptr(), part.vec.data_ptr(), part.heads, part.grids.data_ptr(),
                                                      part.need.data_ptr())
             e2.record(part.stream)
     part.synchronize()
     part.ticks += reps
-    tower = statistics.median(e0.elapsed_time(e1) for e0, e1, e2 in ev[8:])
-    search = statistics.median(e1.elapsed_time(e2) for e0, e1, e2 in ev[8:])
+    over = statistics.median(e1.elapsed_time(e1b) for e0, e1, e1b, e2 in ev[8:])
+    tower = statistics.median(e0.elapsed_time(e1) for e0, e1, e1b, e2 in ev[8:]) - over
+    search = statistics.median(e1b.elapsed_time(e2) for e0, e1, e1b, e2 in ev[8:]) - over
     for p in getattr(sp, "parts", [sp])[1:]:                # the other groups make the same number of ticks: lock-step rounds
         p.tick(reps)
         p.synchronize()

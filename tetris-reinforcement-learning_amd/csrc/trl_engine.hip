@@ -438,8 +438,11 @@ int trl_env_rollout_random(trl_engine *h, int n_plies, int max_plies, uint64_t *
     char *blk = reinterpret_cast<char *>(h->d_steps) + (size_t)h->pp * h->pp_stride;
     char *nxt = reinterpret_cast<char *>(h->d_steps) + (size_t)(h->pp ^ 1) * h->pp_stride;
     h->pp ^= 1;
+    // probe knob: extra LDS per workgroup = fewer workgroups per CU at a time (the rest are dispatched as others finish)
+    unsigned lds_pad = 0;
+    if (const char *e = getenv("TRL_ROLLOUT_LDS_PAD")) lds_pad = (unsigned)atoi(e);
     HIPCHK(hipEventRecord(h->ev0, h->stream));
-    hipLaunchKernelGGL(k_rollout, dim3(h->cfg.n_games), dim3(BLOCK), 0, h->stream, h->d_states, h->cfg.seed,
+    hipLaunchKernelGGL(k_rollout, dim3(h->cfg.n_games), dim3(BLOCK), lds_pad, h->stream, h->d_states, h->cfg.seed,
                        n_plies, max_plies, reinterpret_cast<unsigned long long *>(blk), reinterpret_cast<unsigned int *>(blk + 16),
                        rankt, reinterpret_cast<unsigned long long *>(nxt), reinterpret_cast<unsigned int *>(nxt + 16));
     HIPCHK(hipGetLastError());
