@@ -229,6 +229,9 @@ def bench_mcts(args, rank, local_rank, world, dist, dev, barrier):
                                "(playout cap 400/80, root noise, temperature), AlphaSame blocks=10 filters=16 random init"
                                % n, "games_per_gpu": n, "ticks_timed": args.mcts_ticks, "moves_timed": moves_total,
                    "simulations_timed": sims_total, "slot_groups": groups,
+                   # leaves whose mover's board had been evaluated earlier in the same search (the same placement under
+                   # another reply of the opponent): their tower output comes from the search's board table, not the tower
+                   "leaf_boards_from_the_board_table": round((st1["boards_reused"] - st0["boards_reused"]) / max(sims, 1), 3),
                    "records_to_rank0_mb": round(gathered / 1e6, 1),
                    "parallelism": "games sharded by rank; move records gathered to rank 0 (dist.gather, GPU to GPU) in the timed region"},
         "roofline": roofline,
@@ -259,8 +262,8 @@ def bench_c5(args, rank, local_rank, world, dist, dev, barrier):
     net = trl.AlphaSame(mc)
     cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=800, training=True,
                      use_forced_playouts_and_policy_target_pruning=True)
-    sp = trl.SelfPlay(cfg, net, n, seed=SEED, device=local_rank, streams=parallel.game_streams(rank, n),
-                      auto_reset=True, use_graph=True, record_capacity=1 << 16)
+    sp = trl.make_self_play(cfg, net, n, seed=SEED, device=local_rank, streams=parallel.game_streams(rank, n),
+                            auto_reset=True, use_graph=True, record_capacity=1 << 16)
     sp.tick(args.c5_warmup)
     sp.drain()
     st0 = sp.stats()
@@ -278,7 +281,8 @@ def bench_c5(args, rank, local_rank, world, dist, dev, barrier):
     st1 = sp.stats()
     if st1["overflow"] or st1["records_dropped"] or st1.get("tower_overflow"):
         raise SystemExit("tree / record capacity (or the split towers' activation range) overflowed during the C5 benchmark: results invalid")
-    boards = sp.grids.reshape(2 * n, 1, 40, 10)
+    boards = sp.grids.reshape(-1, 1, 40, 10)               # one tower launch of the tick: both boards of a group's slots
+    nb = boards.shape[0]
     with torch.cuda.stream(sp.stream):
         sp.net._trunk_hip(boards, sp.net._folded["packed_tower"])       # the launch alone (trunk() also waits and reads the range guard)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -292,9 +296,9 @@ def bench_c5(args, rank, local_rank, world, dist, dev, barrier):
     elapsed, moves_total = parallel.reduce_job(elapsed, st1["moves"] - st0["moves"], dist, dev)
     _, sims_total = parallel.reduce_job(elapsed, st1["simulations"] - st0["simulations"], dist, dev)
     split = getattr(sp.net, "tower_mode", "fp32") == "split"
-    algo_tflops = WIDE_FLOP_PER_BOARD * 2 * n / (trunk_ms * 1e-3) / 1e12
+    algo_tflops = WIDE_FLOP_PER_BOARD * nb / (trunk_ms * 1e-3) / 1e12
     if split:
-        tflops, peak, kname = WIDE_SPLIT_FLOP_PER_BOARD * 2 * n / (trunk_ms * 1e-3) / 1e12, MFMA_F16_PEAK_TFLOPS, "k_trunk_wide_s<64>"
+        tflops, peak, kname = WIDE_SPLIT_FLOP_PER_BOARD * nb / (trunk_ms * 1e-3) / 1e12, MFMA_F16_PEAK_TFLOPS, "k_trunk_wide_s<64>"
     else:
         tflops, peak, kname = algo_tflops, MFMA_F32_PEAK_TFLOPS, "k_trunk_wide<64>"
     return {
@@ -305,14 +309,19 @@ def bench_c5(args, rank, local_rank, world, dist, dev, barrier):
         "config": {"workload": "C5: %d concurrent self-play games per GPU, MAX_ITER=800, training=True (playout cap "
                                "2000/400), forced playouts + policy-target pruning, AlphaSame blocks=20 filters=64 random init"
                                % n, "games_per_gpu": n, "ticks_timed": args.c5_ticks, "moves_completed": moves_total,
-                   "simulations_timed": sims_total},
+                   "simulations_timed": sims_total, "slot_groups": len(getattr(sp, "parts", [sp])),
+                   "leaf_boards_from_the_board_table": round((st1["boards_reused"] - st0["boards_reused"]) /
+                                                             max(st1["simulations"] - st0["simulations"], 1), 3)},
         "roofline": {"bound": "mfma", "achieved": round(tflops, 2), "peak": peak, "unit": "TFLOP/s",
                      "frac": round(tflops / peak, 4), "traffic": None, "kernel": kname,
                      "kernel_ms": round(trunk_ms, 4), "flop_per_board": WIDE_SPLIT_FLOP_PER_BOARD if split else WIDE_FLOP_PER_BOARD,
-                     "boards_per_launch": 2 * n, "algorithmic_tflops": round(algo_tflops, 2),
+                     "boards_per_launch": nb, "algorithmic_tflops": round(algo_tflops, 2),
                      "algorithmic_flop_per_board": WIDE_FLOP_PER_BOARD,
                      "note": ("f16 matrix instructions on split fp32 operands (3 products per multiply): the algorithmic rate is %.2f x "
-                              "the fp32 matrix peak of %.1f TFLOP/s" % (algo_tflops / MFMA_F32_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS))
+                              "the fp32 matrix peak of %.1f TFLOP/s; kernel_ms = one launch over ALL boards of a slot group, timed "
+                              "alone after the run -- inside a tick the tower evaluates only the boards that are neither cached "
+                              "from the parent position nor in the search's board table"
+                              % (algo_tflops / MFMA_F32_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS))
                              if split else "fp32 matrix instructions"},
     }
 

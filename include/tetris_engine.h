@@ -273,6 +273,8 @@ typedef struct trl_mcts_stats {
     uint64_t records_dropped;         /* records lost because the device buffer was full */
     uint32_t max_nodes_used;          /* high-water mark of tree nodes in any slot */
     uint32_t overflow;                /* a slot exceeded max_nodes (its search was cut short) */
+    uint64_t boards_reused;           /* leaf boards whose tower output was taken from the search's board table instead of
+                                       * the tower: the same board reached under another reply of the opponent */
 } trl_mcts_stats;
 
 /* attach search state to an engine whose games are set up (trl_env_reset / trl_env_set_state) */
@@ -360,7 +362,7 @@ int  trl_mcts_drain_records_dev(trl_engine *h, trl_record *dev_out, int cap, int
  * slot_offset (a slot group's first global slot), and the pending count cleared -- all queued on the engine's stream, the
  * call returns at once.  dev_head: uint64[9] on the device, zeroed by the caller before the first call;
  * [0] = records in dev_out, [1..8] = the search counters as of this drain: simulations, moves, games, records_dropped,
- * max_nodes_used, overflow, ticks, reserved.  A job that ticks in chunks queues the next chunk behind this call and
+ * max_nodes_used, overflow, ticks, boards_reused.  A job that ticks in chunks queues the next chunk behind this call and
  * reads dev_head / dev_out of the previous one on another stream: the device never waits for the host (the reference's
  * loop appends a move's record to the game's list as it is played, ai.py:1613-1660; this is that list leaving the
  * search's buffer). */

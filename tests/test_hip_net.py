@@ -839,3 +839,41 @@ def test_legal_moves_in_the_tower_launch_keep_their_order():
     ra, rb = a.drain(), b.drain()                                  # (in the order the slots' workgroups got there)
     ra, rb = (r[np.lexsort((r["kind"], r["ply"], r["episode"], r["slot"]))] for r in (ra, rb))
     assert len(ra) == len(rb) > 48 and ra.tobytes() == rb.tobytes()
+
+
+def test_boards_the_tower_has_seen_are_not_evaluated_again(monkeypatch):
+    """The search's board table (DevMcts::btab): a leaf whose mover's board was evaluated earlier in the same search --
+    the same placement under another reply of the opponent -- takes that tower output from the per-state cache instead of
+    the tower.  Same function of the same board, so the games are the same byte for byte as with TRL_BOARD_TABLE=0, and
+    about half of a 160-simulation search's boards are such repeats; with the default net family (k_zcache flow) as well."""
+    torch.manual_seed(0)
+    mc = trl.AlphaSameConfig(blocks=10, filters=16)
+    net = trl.AlphaSame(mc).cuda().prepare()
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=160, training=True)
+    out = []
+    for table in ("1", "0"):
+        monkeypatch.setenv("TRL_BOARD_TABLE", table)
+        sp = trl.SelfPlay(cfg, net, 192, seed=20260630, auto_reset=True, record_capacity=1 << 14)
+        assert sp.fused_select and sp.legal_in_tower
+        sp.tick(520)
+        st = sp.stats()
+        assert st["overflow"] == 0 and st["records_dropped"] == 0 and st["tower_overflow"] == 0
+        out.append((_sorted_records(sp), st))
+    (a, sa), (b, sb) = out
+    assert sb["boards_reused"] == 0 and sa["boards_reused"] > 0.3 * sa["simulations"], (sa, sb)
+    assert sa["moves"] == sb["moves"] > 192 and a.tobytes() == b.tobytes()
+
+    mc = trl.BaseResNetConfig(blocks=2, filters=32, opp_hidden=16, own_kernels=4, value_hidden=8)
+    net = trl.BaseResNet(mc)
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=48, training=True)
+    out = []
+    for table in ("1", "0"):
+        monkeypatch.setenv("TRL_BOARD_TABLE", table)
+        sp = trl.SelfPlay(cfg, net, 64, seed=21)
+        assert sp.tower_cache and sp.heads is None
+        sp.tick(300)
+        st = sp.stats()
+        out.append((_sorted_records(sp), st))
+    (a, sa), (b, sb) = out
+    assert sb["boards_reused"] == 0 and sa["boards_reused"] > 0
+    assert len(a) == len(b) > 64 and a.tobytes() == b.tobytes()

@@ -118,6 +118,7 @@ struct SlotCtl {
     // what the selection knows and the expand would otherwise re-load through dependent global reads: the leaf's side to
     // move, and its parent's node index and child range (FPU refresh of the siblings, ai.py:536-565)
     int32_t leaf_turn, par_node, par_first, par_n;
+    int32_t leaf_zsrc, reserved_;             // >= 0: state (| player << 30) whose cached tower output is the mover's board's (DevMcts::btab)
     int32_t depth, random_move;               // nodes on the selection path root .. leaf (DevMcts::path); this search picks a
     double  terminal_value;                   // random starting move (ai.py:1588-1608)
     double  rand_left;                        // num_random_moves still to play in this game

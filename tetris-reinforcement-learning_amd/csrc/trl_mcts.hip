@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <new>
+#include <stdlib.h>
 #include "trl_internal.h"
 
 using namespace trl;
@@ -50,7 +51,15 @@ struct DevMcts {
     unsigned int *rec_count;
     float *zcache;              // [n_games][cap_states][2 players][zdim]: tower output per expanded position and board
     int zdim;                   // floats per board: 400 for AlphaSame; (own_kernels + 1) * 400 for the BaseResNet family
-    unsigned long long *counters;   // 0 simulations, 1 moves, 2 games, 3 dropped, 4 max nodes, 5 overflow, 6 ticks
+    unsigned long long *counters;   // 0 simulations, 1 moves, 2 games, 3 dropped, 4 max nodes, 5 overflow, 6 ticks, 7 board-table hits
+    // Boards the tower has seen in the slot's current search: [n_games][btab_size] open-addressed words
+    //   hash32 (never 0) | (state index | player << 30) << 32,   all zero = empty; cleared when a search begins.
+    // A move changes the mover's board only, and how it changes depends on that board and the move alone, so under
+    // different replies of the other player the same board comes up again and again: half of the boards a 160-simulation
+    // search sends to the tower (three quarters in a 2000-simulation one) have been there before -- their output is in
+    // the per-state cache already.  Candidates are confirmed row by row against the stored position (no trust in the hash).
+    unsigned long long *btab;
+    int btab_size;                  // power of two >= 2 * cap_states; 0: no table
 };
 
 // ---- random draws of the search -----------------------------------------------------------------
@@ -182,13 +191,17 @@ static __device__ __forceinline__ void select_body(SH &sh, const DevMcts &M, trl
                     c.max_iter = (int)ceil(cfg.playout_cap_mult * (cfg.max_iter / denom));
                 else { c.max_iter = (int)floor(cfg.max_iter / denom); c.fast = 1; }
             } else c.max_iter = cfg.max_iter;
-            c.iter = 0; c.n_nodes = 1; c.n_states = 1; c.phase = 1; c.overflow = 0;
+            c.iter = 0; c.n_nodes = 1; c.n_states = 1; c.phase = 1; c.overflow = 0; c.leaf_zsrc = -1;
             M.t.parent[nb] = -1; M.t.first[nb] = -1; M.t.nchild[nb] = 0; M.t.move[nb] = TRL_MOVE_NONE;
             M.t.visit[nb] = 0; M.t.wsum[nb] = 0.0; M.t.q[nb] = 0.0; M.t.prior[nb] = 0.0; M.t.state[nb] = 0;
             M.t.pf32[nb] = 0; M.t.turn[nb] = g.turn;
         }
         __syncthreads();
         copy_state(pool, &sh.b.g, tid);
+        if (M.btab_size) {
+            unsigned long long *bt = M.btab + (size_t)slot * M.btab_size;
+            for (int i = tid; i < M.btab_size; i += BLOCK) bt[i] = 0ull;
+        }
         __syncthreads();
     }
 
@@ -289,6 +302,36 @@ static __device__ __forceinline__ void select_body(SH &sh, const DevMcts &M, trl
         } else if (tid == 0) sh.b.overflow = 0;
     }
 
+    // has the tower seen the mover's board in this search?  (wave 0; the other wave goes on to the features)
+    int zsrc = -1;
+    if (need && M.btab_size && kind != 2 && node != 0 && tid < 64) {
+        const int mover = 1 - g.turn;
+        const uint32_t myrow = lane < TRL_ROWS ? (uint32_t)g.p[mover].rows[lane < TRL_ROWS ? lane : 0] : 0u;
+        uint32_t hsh = (myrow + 1u) * (0x9E3779B1u * (2u * (uint32_t)lane + 1u));
+#pragma unroll
+        for (int off = 32; off; off >>= 1) hsh += (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ off) << 2, (int)hsh);
+        hsh ^= hsh >> 15; hsh *= 0x2C1B3C6Du; hsh ^= hsh >> 12;
+        if (hsh == 0u) hsh = 1u;
+        unsigned long long *bt = M.btab + (size_t)slot * M.btab_size;
+        const unsigned int mask = (unsigned int)M.btab_size - 1u;
+        // eight consecutive words in one read (lanes 0..7); never deleted from, so any match in the window counts
+        const unsigned long long e = lane < 8 ? bt[(hsh + (unsigned int)lane) & mask] : ~0ull;
+        uint64_t cand = __ballot(lane < 8 && (uint32_t)e == hsh);
+        const uint64_t empty = __ballot(lane < 8 && e == 0ull);
+        while (cand) {
+            const int L = __ffsll((unsigned long long)cand) - 1;
+            cand &= cand - 1;
+            const uint32_t ref = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(e >> 32), L);
+            const int cs = (int)(ref & 0x3FFFFFFFu), cp = (int)(ref >> 30) & 1;
+            const uint32_t theirs = lane < TRL_ROWS ? (uint32_t)pool[cs].p[cp].rows[lane < TRL_ROWS ? lane : 0] : 0u;
+            if (!__ballot(theirs != myrow)) { zsrc = (int)ref; break; }
+        }
+        if (zsrc < 0 && empty) {
+            const int L = __ffsll((unsigned long long)empty) - 1;
+            if (lane == L) bt[(hsh + (unsigned int)lane) & mask] = (unsigned long long)hsh | ((unsigned long long)((uint32_t)sidx | ((uint32_t)mover << 30)) << 32);
+        }
+    }
+
     // game_to_X (ai.py:1364-1413): side to move first
     MPROF_T(ms4); MPROF_ADD(3, ms3, ms4);
     {
@@ -323,11 +366,13 @@ static __device__ __forceinline__ void select_body(SH &sh, const DevMcts &M, trl
         c.leaf = node; c.leaf_kind = kind; c.leaf_nlegal = nlegal; c.leaf_state = sidx; c.leaf_parent_state = pstate;
         c.depth = depth;
         c.leaf_turn = g.turn; c.par_node = par_node; c.par_first = par_first; c.par_n = par_n;
+        c.leaf_zsrc = zsrc;
+        if (zsrc >= 0) atomicAdd(&M.counters[7], 1ull);
         if (need) {
             // which boards need the tower: a move changes only the mover's board (game.py:66-118), so the side to
             // move at the leaf keeps the tower output its board had in the parent position (trl_mcts_zcache)
             need[slot] = (kind != 2 && node == 0) ? 1 : 0;                    // grids[0]: side to move
-            need[M.n_games + slot] = (kind != 2) ? 1 : 0;                     // grids[1]: the player who just moved
+            need[M.n_games + slot] = (kind != 2 && zsrc < 0) ? 1 : 0;         // grids[1]: the player who just moved (unless seen: btab)
         }
         if (kind == 2) {
             int w = g.p[0].game_over ? 1 : (g.p[1].game_over ? 0 : -1);      // Game.winner, game.py:217-225
@@ -407,9 +452,11 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
         const int q = sh.ctl.leaf_turn, ps = sh.ctl.leaf_parent_state;        // (= pool[leaf_state].turn)
         float *zc = M.zcache + ((size_t)slot * M.cap_states) * 800;
         float *mine = zc + (size_t)sh.ctl.leaf_state * 800;
+        const int zs = sh.ctl.leaf_zsrc;                                      // the mover's board was evaluated before (btab)
+        const float *osrc = zs >= 0 ? zc + (size_t)(zs & 0x3FFFFFFF) * 800 + ((zs >> 30) & 1) * 400 : z + ((size_t)M.n_games + slot) * 400;
         for (int i = tid; i < 400; i += NT) {
             float a = (ps < 0) ? z[(size_t)slot * 400 + i] : zc[(size_t)ps * 800 + q * 400 + i];
-            float o = z[((size_t)M.n_games + slot) * 400 + i];
+            float o = osrc[i];
             sh.xs[i] = a; sh.zo[i] = o;
             mine[q * 400 + i] = a; mine[(1 - q) * 400 + i] = o;
         }
@@ -869,9 +916,12 @@ __global__ __launch_bounds__(128) void k_zcache(DevMcts M, float *z) {
     float *zc = M.zcache + ((size_t)slot * M.cap_states) * 2 * zd;
     float *mine = zc + (size_t)c.leaf_state * 2 * zd;
     float *za = z + (size_t)slot * zd, *zo = z + ((size_t)M.n_games + slot) * zd;
+    const int zs = c.leaf_zsrc;
+    const float *osrc = zs >= 0 ? zc + (size_t)(zs & 0x3FFFFFFF) * 2 * zd + ((zs >> 30) & 1) * zd : zo;
     for (int i = tid; i < zd; i += 128) {
         float a = (c.leaf_parent_state < 0) ? za[i] : zc[(size_t)c.leaf_parent_state * 2 * zd + q * zd + i];
-        float o = zo[i];
+        float o = osrc[i];
+        zo[i] = o;
         za[i] = a;
         mine[q * zd + i] = a;
         mine[(1 - q) * zd + i] = o;
@@ -945,7 +995,7 @@ static void free_dev(DevMcts &d) {
     hipFree(d.t.parent); hipFree(d.t.first); hipFree(d.t.visit); hipFree(d.t.state); hipFree(d.t.nchild); hipFree(d.t.move);
     hipFree(d.t.wsum); hipFree(d.t.q); hipFree(d.t.prior); hipFree(d.t.pf32); hipFree(d.t.turn);
     hipFree(d.ctl); hipFree(d.pool); hipFree(d.leaf_moves); hipFree(d.path); hipFree(d.recs); hipFree(d.rec_count); hipFree(d.counters);
-    hipFree(d.zcache);
+    hipFree(d.zcache); hipFree(d.btab);
 }
 
 void trl_mcts_free_internal(trl_engine *h) {
@@ -972,6 +1022,10 @@ static int mcts_alloc(trl_engine *h, trl_mcts *m) {
     HIPCHK(hipMalloc(&d.path, n * PATH_CAP * sizeof(int32_t)));
     d.zdim = 400;
     HIPCHK(hipMalloc(&d.zcache, n * d.cap_states * 2 * d.zdim * sizeof(float)));
+    if (d.btab_size) {
+        HIPCHK(hipMalloc(&d.btab, n * (size_t)d.btab_size * sizeof(unsigned long long)));
+        HIPCHK(hipMemsetAsync(d.btab, 0, n * (size_t)d.btab_size * sizeof(unsigned long long), h->stream));
+    }
     HIPCHK(hipMalloc(&d.recs, (size_t)d.rec_cap * sizeof(trl_record)));
     HIPCHK(hipMalloc(&d.rec_count, 4));
     HIPCHK(hipMalloc(&d.counters, 8 * 8));
@@ -1018,6 +1072,11 @@ int trl_mcts_create(trl_engine *h, const trl_mcts_config *cfg) {
         return fail(TRL_E_INVALID, "trl_mcts_create: %s", "at most 256 episodes per slot (RNG stream = slot stream + episode * 2^24)");
     }
     d.cap_states = longest + 2;
+    d.btab_size = 0;
+    {   // TRL_BOARD_TABLE=0: every leaf's board goes to the tower (A/B runs and the tests that compare the two)
+        const char *e = getenv("TRL_BOARD_TABLE");
+        if (!e || atoi(e) != 0) { d.btab_size = 64; while (d.btab_size < 2 * d.cap_states) d.btab_size <<= 1; }
+    }
     // default tree capacity: one expansion per simulation, ~50 children each (measured: 20.5 k nodes after 400
     // simulations), with headroom; never below 65 536
     d.max_nodes = cfg->max_nodes > 0 ? cfg->max_nodes : (longest * 96 > DEFAULT_MAX_NODES ? longest * 96 : DEFAULT_MAX_NODES);
@@ -1285,6 +1344,7 @@ int trl_mcts_get_stats(trl_engine *h, trl_mcts_stats *out) {
     HIPCHK(hipStreamSynchronize(h->stream));
     out->ticks = c[6]; out->simulations = c[0]; out->moves = c[1]; out->games = c[2];
     out->records_dropped = c[3]; out->max_nodes_used = (uint32_t)c[4]; out->overflow = (uint32_t)c[5];
+    out->boards_reused = c[7];
     return TRL_OK;
 }
 

@@ -979,16 +979,13 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     return v;
 }
 
+// one board through the tower; all threads of the workgroup call it with the same board (`lds`: W::LDS_FLOATS floats)
 template <int FF, bool POST>
-__global__ __launch_bounds__((WideS<FF>::THREADS), 2) void k_trunk_wide_s(const float *__restrict__ boards,
-                                                                       const float *__restrict__ wts, int n_blocks,
-                                                                       float *__restrict__ out,
-                                                                       const uint8_t *__restrict__ need, int kout) {
+static __device__ __forceinline__ void trunk_wide_s_board(const float *__restrict__ boards, const float *__restrict__ wts, int n_blocks,
+                                                          float *__restrict__ out, int kout, const size_t board, float *lds) {
     using W = WideS<FF>;
     constexpr int TS = W::TS, NN = W::NN, THREADS = W::THREADS;
     constexpr int STEM = POST ? 9 : 25, STEM_STEPS = (STEM + 3) / 4;
-    if (need && !need[blockIdx.x]) return;
-    __shared__ __attribute__((aligned(16))) float lds[W::LDS_FLOATS];
     _Float16 *hiP = reinterpret_cast<_Float16 *>(lds), *loP = hiP + W::LO;
     float *brd = lds + W::PLANES_FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -996,7 +993,6 @@ __global__ __launch_bounds__((WideS<FF>::THREADS), 2) void k_trunk_wide_s(const 
     const int g = lane >> 4, pn = lane & 15;              // result layout: channels 4 g + r of the group at tile position pn
     const int cgroup = wave % NN, mq = wave / NN;
     const int ch4 = cgroup * 16 + 4 * g;                  // the lane's first channel
-    const size_t board = blockIdx.x;
 
     for (int i = tid; i < W::LDS_FLOATS / 4; i += THREADS) reinterpret_cast<f32x4 *>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
@@ -1154,6 +1150,47 @@ __global__ __launch_bounds__((WideS<FF>::THREADS), 2) void k_trunk_wide_s(const 
     }
 }
 
+// COMPACT = false: workgroup b takes board b (boards with need == 0 end at once).
+// COMPACT = true (launches with need flags): workgroup b takes the b-th LIVE board.  A workgroup of this kernel owns its CU
+// (138 KB of LDS at 64 filters), so a workgroup that only looks at its flag still queues for a CU behind the ones that
+// work; with the live boards scattered over the grid a search tick whose boards are mostly cached (the search's board table:
+// 60-70 % at MAX_ITER = 800) pays for rounds of workgroups it does not need.  With the live boards in front the dispatcher
+// packs them ceil(live / CUs) deep and the idle workgroups run out behind them.  Every workgroup builds the list for itself
+// from the need flags (n_boards bytes, one read, two barriers).
+template <int FF, bool POST, bool COMPACT>
+__global__ __launch_bounds__((WideS<FF>::THREADS), 2) void k_trunk_wide_s(const float *__restrict__ boards,
+                                                                       const float *__restrict__ wts, int n_blocks,
+                                                                       float *__restrict__ out,
+                                                                       const uint8_t *__restrict__ need, int kout, int n_boards) {
+    using W = WideS<FF>;
+    __shared__ __attribute__((aligned(16))) float lds[W::LDS_FLOATS];
+    if (!COMPACT) {
+        if (need && !need[blockIdx.x]) return;
+        trunk_wide_s_board<FF, POST>(boards, wts, n_blocks, out, kout, (size_t)blockIdx.x, lds);
+        return;
+    }
+    __shared__ int wave_cnt[W::THREADS / 64], mine_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) mine_sh = -1;
+    int seen = 0;                                                          // live boards before this chunk
+    for (int base = 0; base < n_boards && seen <= (int)blockIdx.x; base += W::THREADS) {
+        const int b = base + tid;
+        const bool on = b < n_boards && need[b] != 0;
+        const uint64_t m = __ballot(on);
+        if (lane == 0) wave_cnt[wave] = __popcll(m);
+        __syncthreads();
+        int off = seen, total = seen;
+        for (int w = 0; w < W::THREADS / 64; w++) { const int c = wave_cnt[w]; if (w < wave) off += c; total += c; }
+        if (on && off + __popcll(m & ((1ull << lane) - 1ull)) == (int)blockIdx.x) mine_sh = b;      // the blockIdx-th live board
+        __syncthreads();
+        seen = total;
+    }
+    const int board = mine_sh;
+    if (board < 0) return;                                                 // fewer live boards than workgroups: nothing to do
+    __syncthreads();
+    trunk_wide_s_board<FF, POST>(boards, wts, n_blocks, out, kout, (size_t)board, lds);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1248,8 +1285,14 @@ int trl_trunk_wide_split(const float *dev_boards, int n_boards, const float *dev
     hipStream_t st = (hipStream_t)stream;
     if (filters != 32 && filters != 64)
         return fail(TRL_E_INVALID, "trl_trunk_wide_split: %s", "the split wide tower exists for 32 and 64 filters");
-#define TRL_LAUNCH_WS(FF_, POST_) hipLaunchKernelGGL((k_trunk_wide_s<FF_, POST_>), dim3(n_boards), dim3(WideS<FF_>::THREADS), \
-                                                     0, st, dev_boards, dev_packed, n_blocks, dev_out, dev_need, resnet ? kout : 1)
+    // with need flags: the live boards first (k_trunk_wide_s<.., COMPACT>); TRL_WIDE_COMPACT=0: workgroup b = board b
+    static const int compact_on = getenv("TRL_WIDE_COMPACT") ? atoi(getenv("TRL_WIDE_COMPACT")) : 1;
+    const bool persist = compact_on && dev_need;
+    const int grid = n_boards;
+#define TRL_LAUNCH_WS(FF_, POST_) do { if (persist) hipLaunchKernelGGL((k_trunk_wide_s<FF_, POST_, true>), dim3(grid), dim3(WideS<FF_>::THREADS), \
+                                                     0, st, dev_boards, dev_packed, n_blocks, dev_out, dev_need, resnet ? kout : 1, n_boards); \
+                                       else hipLaunchKernelGGL((k_trunk_wide_s<FF_, POST_, false>), dim3(grid), dim3(WideS<FF_>::THREADS), \
+                                                     0, st, dev_boards, dev_packed, n_blocks, dev_out, dev_need, resnet ? kout : 1, n_boards); } while (0)
     if (filters == 64) { if (resnet) TRL_LAUNCH_WS(64, true); else TRL_LAUNCH_WS(64, false); }
     else { if (resnet) TRL_LAUNCH_WS(32, true); else TRL_LAUNCH_WS(32, false); }
 #undef TRL_LAUNCH_WS

@@ -74,7 +74,8 @@ class TrlAlphaSameHeads(C.Structure):
 
 class TrlMctsStats(C.Structure):
     _fields_ = [("ticks", C.c_uint64), ("simulations", C.c_uint64), ("moves", C.c_uint64), ("games", C.c_uint64),
-                ("records_dropped", C.c_uint64), ("max_nodes_used", C.c_uint32), ("overflow", C.c_uint32)]
+                ("records_dropped", C.c_uint64), ("max_nodes_used", C.c_uint32), ("overflow", C.c_uint32),
+                ("boards_reused", C.c_uint64)]
 
 
 

@@ -122,7 +122,7 @@ def derive_seed(base, *parts):
 # ---- the tick loop ----------------------------------------------------------------------------------------
 FUSE_SELECT = os.environ.get("TRL_FUSE_SELECT", "1") != "0"   # native tick: expand + next select as one launch
 DRAIN_HEAD_WORDS = 9            # trl_mcts_drain_records_async's dev_head: [0] records, [1..8] search counters at that drain
-DRAIN_HEAD_FIELDS = ("simulations", "moves", "games", "records_dropped", "max_nodes_used", "overflow", "ticks")
+DRAIN_HEAD_FIELDS = ("simulations", "moves", "games", "records_dropped", "max_nodes_used", "overflow", "ticks", "boards_reused")
 LEGAL_IN_TOWER = os.environ.get("TRL_LEGAL_IN_TOWER", "1") != "0"   # the fused tick's legal-move search in its tower launch
 GRAPH_TICKS = int(os.environ.get("TRL_GRAPH_TICKS", "8"))      # ticks per launch of the long tick graph (1: single-tick graph only)
 
@@ -492,8 +492,7 @@ class SelfPlayGroups:
 def slot_groups(config, network, n_slots):
     """how many groups a job's slots are ticked in: TRL_SLOT_GROUPS, or where it pays -- the all-native tick of a
     16-filter AlphaSame (two tower workgroups per CU leave registers for the search kernel): 4 groups from 1024 slots
-    (C3: 0.160 ms per round of ticks against 0.177 with 2 and 0.20 with 1), 2 from 512; the 64-filter tower owns its CU
-    (138 KB of LDS, 500 registers per SIMD) and gains nothing"""
+    (C3: 0.160 ms per round of ticks against 0.177 with 2 and 0.20 with 1), 2 from 512; the 64-filter AlphaSame: 2 from 1024"""
     env = os.environ.get("TRL_SLOT_GROUPS", "auto")
     if env != "auto":
         return max(1, int(env))
@@ -501,6 +500,12 @@ def slot_groups(config, network, n_slots):
     native16 = type(network).__name__ == "AlphaSame" and getattr(mc, "filters", 0) == 16 and getattr(mc, "kernels", 1) == 1
     if native16 and n_slots >= 1024 and n_slots % 4 == 0:
         return 4
+    # the 64-filter tower owns its CU (138 KB of LDS), but since the search's board table leaves it only a third of the
+    # leaves' boards, a launch over one group's live boards ends in a partly filled round of workgroups -- which the other
+    # group's launch fills (C5, 1024 slots: 0.81 -> 1.03 M simulations/s with two groups, 1.00 with four)
+    native64 = type(network).__name__ == "AlphaSame" and getattr(mc, "filters", 0) == 64 and getattr(mc, "kernels", 1) == 1
+    if native64 and n_slots >= 1024 and n_slots % 2 == 0 and getattr(network, "tower_mode", "") == "split":
+        return 2
     return 2 if (native16 and n_slots >= 512 and n_slots % 2 == 0) else 1
 
 
