@@ -155,6 +155,7 @@ __device__ __forceinline__ void emit_flagged(MgScratch &S, bool emit, int rot, i
 
 #ifdef TRL_PROFILE
 static __device__ unsigned long long g_prof[16];
+static __device__ unsigned long long g_cprof[16];   // closure search: 0 set-up, 1 fixed point, 2 kicks, 3 planes + list, 4 mixed stage, 8 searches, 9 fixed-point steps, 10 kick rounds, 11 kick probes
 #define PROF_T(v) unsigned long long v = __builtin_readcyclecounter()
 #define PROF_ADD(i, a, b) do { prof_acc[i] += (b) - (a); } while (0)
 #else
@@ -595,6 +596,15 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
                                                            uint16_t *out, int out_cap, int lane, int *overflow) {
     const int rot = lane >> 4, mx = lane & 15;
     const bool isT = (type == PT), check_rot = (type != PO);
+#ifdef TRL_PROFILE
+    unsigned long long cp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define CPROF_FLUSH() do { if (lane == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd(&g_cprof[i_], cp[i_]); } while (0)
+#define CPROF_ADD(i, a, b) do { cp[i] += (b) - (a); } while (0)
+#else
+#define CPROF_FLUSH()
+#define CPROF_ADD(i, a, b)
+#endif
+    PROF_T(c_0);
     // free cells per board column: ten ballots over the rows (lane = board row), column x kept by lane x + 2
     const uint32_t myrow = lane < TRL_ROWS ? (uint32_t)rows[lane < TRL_ROWS ? lane : 0] : 0x3FFu;
     uint64_t mine = 0;
@@ -643,14 +653,18 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
     const uint64_t edge = valid & (~(valid >> 1) | ~dpp64(valid, 0) | ~dpp64(valid, 1));
     uint64_t reach = (lane == sx + 2) ? (1ull << (sy + 2)) : 0ull;
     uint64_t done = 0;
+    PROF_T(c_1); CPROF_ADD(0, c_0, c_1); CPROF_ADD(8, 0ull, 1ull);
     for (int round = 0;; round++) {
+        PROF_T(c_f0);
         // fixed point under down / left / right inside every rotation state
         for (;;) {
             const uint64_t old = reach;
             reach |= ((valid + reach) ^ valid) & valid;                                  // down: carry chain through the valid run
             reach |= (dpp64(reach, 0) | dpp64(reach, 1)) & valid;                        // one column to either side
+            CPROF_ADD(9, 0ull, 1ull);
             if (!__ballot(reach != old)) break;
         }
+        PROF_T(c_f1); CPROF_ADD(1, c_f0, c_f1);
         if (!check_rot) break;
         // T: the cells of generation 0 (the spawn region, rotation 0) and of generation <= 1 (resolve_mixed_wave)
         if (isT && round < 2 && (round == 0) == (rot == 0)) C.snap[lane] = reach;
@@ -658,6 +672,7 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
         const uint64_t src = reach & edge & ~done;
         done |= src;
         if (!__ballot(src != 0)) break;
+        PROF_T(c_k0); CPROF_ADD(10, 0ull, 1ull);
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             const int nrot = (rot + d + 1) & 3;
@@ -667,6 +682,7 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
 #pragma unroll 1
             for (int ki = 0; ki < 6; ki++, kq >>= 6) {
                 if (!__ballot(rem != 0 && ki < nk)) break;
+                CPROF_ADD(11, 0ull, 1ull);
                 const int fx = (int)(kq & 7), fy = (int)((kq >> 3) & 7);                 // kick (fx - 2, fy - 2)
                 const int idx = nrot * 20 + mx + fx;                                     // target column mx + kx, + 2
                 const uint64_t vt = C.vcol[idx];
@@ -684,8 +700,10 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
         wave_sync();
         const uint64_t add = (C.arr[0][rot * 20 + mx + 2] | C.arr[1][rot * 20 + mx + 2]) & ~reach;
         reach |= add;
+        PROF_T(c_k1); CPROF_ADD(2, c_k0, c_k1);
         if (!__ballot(add != 0)) break;
     }
+    PROF_T(c_2);
     // placements: cells that cannot move down (:439-440); T: flagged arrivals on such cells (:386-392, 474-480)
     const uint64_t stuck = valid & ~(valid >> 1);
     if (isT) {
@@ -697,6 +715,7 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
             keep[lane] = reach & edge;
             keep[64 + lane] = reach & stuck;
             wave_sync();
+            CPROF_FLUSH();
             return -2;
         }
         scatter_column(&C.flagp[0][0], f1 | f0, rot, mx);
@@ -707,6 +726,8 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
     int total = placements_to_moves(C, type, out, out_cap, lane);
     if (total > out_cap) { *overflow = 1; total = out_cap; }
     wave_sync();
+    PROF_T(c_3); CPROF_ADD(3, c_2, c_3);
+    CPROF_FLUSH();
     return total;
 }
 

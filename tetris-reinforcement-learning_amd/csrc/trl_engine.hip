@@ -476,6 +476,11 @@ int trl_debug_prof(unsigned long long *host_out, int reset) {
     if (reset) { unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(trl::g_prof), z, sizeof z)); }
     return TRL_OK;
 }
+int trl_debug_cprof(unsigned long long *host_out, int reset) {       // closure search (trl_device.h: g_cprof)
+    HIPCHK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(trl::g_cprof), sizeof(unsigned long long) * 16));
+    if (reset) { unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(trl::g_cprof), z, sizeof z)); }
+    return TRL_OK;
+}
 #endif
 
 // test hook (declared in tests only): integer attack formulas, rows int16[n][8] -> out int16[n][4]
