@@ -235,13 +235,11 @@ def resolve_mixed(valid, edge, sel, ktab, reach, snaps, a_last, a_other, stuck):
                 dm[rot][mx] = r
         if not changed:
             break
-    for rot in range(1, 4):
-        for mx in range(MAP_W):
-            if dm[rot][mx] != r1[rot][mx]:
-                return -1
+    # (a state's generation-1 cells may have more pieces than this first flood -- pockets that later items reach; the rule
+    # below needs only the cells it looks at, the mixed cell and its sources, to lie in the first flood)
     settled = 0
     for rK, xK, yK in mixed_cells:
-        inK = ((r0[0][xK] if rK == 0 else r1[rK][xK]) >> yK) & 1
+        inK = ((r0[0][xK] if rK == 0 else dm[rK][xK]) >> yK) & 1
         if not inK:
             return -1
         best = None
@@ -263,7 +261,7 @@ def resolve_mixed(valid, edge, sel, ktab, reach, snaps, a_last, a_other, stuck):
                         return -1
                     t = (1 << 40) | (skey << 21)
                 else:
-                    if not (r1[rs][sx] >> sy) & 1:
+                    if not (dm[rs][sx] >> sy) & 1:
                         return -1
                     visited = rK == 0 or seedkey[rK] < seedkey[rs]
                     t = ((1 << 40) | (seedkey[rs] << 21) | (1 << 20) | skey) if visited else ((2 << 40) | (seedkey[rs] << 21) | skey)

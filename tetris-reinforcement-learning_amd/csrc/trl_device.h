@@ -459,18 +459,18 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v, int lane) {
 // Mixed T cells (flagged arrivals through a last kick AND through another kick: the last flagged writer decides the
 // sub-plane, move_generation.py:671-677) whose last writer follows from the first two generations of the walk, without
 // walking.  The FIFO's order is the order of the pushes; the spawn region (generation 0, rotation 0) is one flood, so the
-// generation-1 items are ordered by the (row, column, direction) of their source cell in it, and as long as each of the
-// other three rotation states' generation-1 cells are flooded by ONE item (the first one pushed into that state), the time
-// of a flagged write is a tuple of map coordinates:
+// generation-1 items are ordered by the (row, column, direction) of their source cell in it, and for the cells of the
+// other three rotation states that the FIRST item pushed into their state floods (nearly all of a state's generation-1
+// cells; pockets that only later items reach are the exception), the time of a flagged write is a tuple of map coordinates:
 //   arrival from a generation-0 source on a cell first visited in generation 1: written when the pushed item is popped
 //       (1, key(source), 0)                                               key = (row, column, direction)
 //   arrival from a generation-1 source s on a cell already visited by then -- a cell of the spawn region, or of a state
 //   whose first item was pushed before s's state's -- written while s's state is flooded
 //       (1, seedkey(rot s), 1, key(s))                                    seedkey = key of the first push into the state
 //   ... on a cell not visited yet: pushed, written when popped in generation 2:   (2, seedkey(rot s), key(s))
-// The latest write wins.  A search with a mixed cell outside these cases (a cell or a source first reached in a later
-// generation, a state flooded in several pieces) is left to the ordered walk (returns false): 4 % of the T searches of the
-// fixture games instead of 21 %.  scripts/bfs_closure_proto.py: resolve_mixed, checked against every fixture list.
+// The latest write wins.  A search with a mixed cell outside these cases (the cell or one of its sources first reached in a
+// later generation, or outside its state's first flood) is left to the ordered walk (returns false): 3.8 % of the T
+// searches of the fixture games instead of 21 %.  scripts/bfs_closure_proto.py: resolve_mixed, checked against every fixture list.
 // C.snap holds the generation snapshots; the three planes (not written yet) lend their memory: the caller has left every
 // lane's reached edge cells in the first 64 words (and what it wants to keep in the next 64).  It starts from LDS alone --
 // nothing of the closure search stays in registers across it (movegen_closure_finish_mixed): the registers of this rare
@@ -513,7 +513,7 @@ static __device__ __forceinline__ bool resolve_mixed_wave(CsScratch &C, int lane
             seed[d] = wave_min_u32(best, lane);
         }
     }
-    // is every state's generation-1 region the flood of its first item?
+    // the flood of the first item pushed into each of the states 1..3
     {
         uint64_t dm = 0;
         if (rot > 0) {
@@ -526,7 +526,11 @@ static __device__ __forceinline__ bool resolve_mixed_wave(CsScratch &C, int lane
             dm |= (dpp64(dm, 0) | dpp64(dm, 1)) & valid;
             if (!__ballot(dm != old)) break;
         }
-        if (__ballot(rot > 0 && dm != C.snap[lane])) return false;
+        // A state's generation-1 cells may have more pieces than this first flood (pockets that later items reach): the
+        // rule needs only the cells it looks at -- the mixed cell and its sources -- to lie in the first flood, so from
+        // here on the snapshot of the states 1..3 IS the first flood (a subset of the generation-1 cells)
+        if (rot > 0) C.snap[lane] = dm;
+        wave_sync();
     }
     // cell by cell: the candidate sources (three other states x up to six kicks) one per lane
     bool ok = true;
