@@ -486,14 +486,17 @@ int trl_debug_cprof(unsigned long long *host_out, int reset) {       // closure 
 // test hook (declared in tests only): integer attack formulas, rows int16[n][8] -> out int16[n][4]
 int trl_debug_attack_table(const int16_t *host_rows, int n, int16_t *host_out) {
     int16_t *d_rows = nullptr, *d_out = nullptr;
-    HIPCHK(hipMalloc(&d_rows, (size_t)n * 16));
-    HIPCHK(hipMalloc(&d_out, (size_t)n * 8));
-    HIPCHK(hipMemcpy(d_rows, host_rows, (size_t)n * 16, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_attack_table, dim3((n + 255) / 256), dim3(256), 0, 0, d_rows, n, d_out);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(host_out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipFree(d_rows));
-    HIPCHK(hipFree(d_out));
+    hipError_t e = hipMalloc(&d_rows, (size_t)n * 16);
+    if (e == hipSuccess) e = hipMalloc(&d_out, (size_t)n * 8);
+    if (e == hipSuccess) e = hipMemcpy(d_rows, host_rows, (size_t)n * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_attack_table, dim3((n + 255) / 256), dim3(256), 0, 0, d_rows, n, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(host_out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost);
+    hipFree(d_rows);                                   // (both buffers go whatever happened above)
+    hipFree(d_out);
+    HIPCHK(e);
     return TRL_OK;
 }
 

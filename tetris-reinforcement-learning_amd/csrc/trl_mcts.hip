@@ -83,7 +83,7 @@ __device__ __forceinline__ double gamma_draw(uint64_t seed, uint32_t stream, uin
             return d * v * exp(log(ub) / a);
         }
     }
-    return 0.0;
+    return -1.0;            // 64 rejections in a row (p < 1e-80): the caller uses 0 and counts the search as overflowed
 }
 // numpy's pairwise float64 sum (np.sum of a contiguous 1-D array, ai.py:600): blocks of at most 128 elements are summed
 // with eight running sums, longer arrays are halved (at a multiple of 8) -- two levels of halving cover n <= 512 =
@@ -666,6 +666,7 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
             for (int k = tid; k < n; k += BLOCK) {
                 const size_t ci = nb + first + k;
                 double noise = gamma_draw(M.seed, stream, (uint64_t)ply * 512 + (uint64_t)k, a);
+                if (noise < 0.0) { noise = 0.0; atomicAdd(&M.counters[5], 1ull); }      // never seen; not silent if it happens
                 double p = M.t.prior[ci];
                 if (M.t.pf32[ci]) p = (double)((float)p * (float)(1 - cfg.dir_expl)) + noise * cfg.dir_expl;
                 else p = p * (1 - cfg.dir_expl) + noise * cfg.dir_expl;
