@@ -637,7 +637,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank) if backend == "nccl" else None
     dist_info = {"backend": None, "world_size": 1}
-    if world > 1:
+    # TRL_DIST_SINGLE_RANK=1: a process group of this one rank -- the N-rank code path (barriers, reductions and the record
+    # gather on the nccl backend with device tensors) rehearsed on a box with one GPU (tests/test_hip_rccl_single.py)
+    single_rank_group = world == 1 and os.environ.get("TRL_DIST_SINGLE_RANK", "0") == "1"
+    if single_rank_group:
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or single_rank_group:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         sys.stderr.write("[bench rank %d/%d] device_count=%d, bound to cuda:%d (%s), backend=%s, master %s:%s\n"

@@ -17,7 +17,11 @@ def dist_env():
 
 
 def active(dist):
-    return dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    """a process group with more than one rank -- or, with TRL_DIST_SINGLE_RANK=1, an initialised group of one: the
+    rehearsal of the multi-rank code path (RCCL calls on device tensors included) on a box with one GPU"""
+    if dist is None or not dist.is_initialized():
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("TRL_DIST_SINGLE_RANK", "0") == "1"
 
 
 def game_streams(rank, games_per_rank, episode_base=0):
