@@ -4,6 +4,9 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import tetris_rl_amd as trl
+if os.environ.get("TRL_ALT_LIB"):                   # A/B runs: another build of the library
+    from tetris_rl_amd import engine
+    engine._lib = engine.load_library(os.environ["TRL_ALT_LIB"])
 ticks = int(sys.argv[1]) if len(sys.argv) > 1 else 800
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 torch.manual_seed(0)
