@@ -623,7 +623,7 @@ static __device__ __forceinline__ void expand_body(ExpandShared &sh, const DevMc
             __syncthreads();
             float rmax = sh.red_f[0];
 #pragma unroll
-            for (int w = 1; w < NW; w++) rmax = fmaxf(rmax, sh.red_f[w]);
+            for (int w = 1; w < BLOCK / 64; w++) rmax = fmaxf(rmax, sh.red_f[w]);   // (only the first two waves are left here)
             const double log_max = log((double)rmax);
             const double inv_temp = 1.0 / cfg.root_softmax_temp;
             for (int k = tid; k < n; k += BLOCK) sh.pd[k] = exp((log((double)sh.pf[k]) - log_max) * inv_temp);
