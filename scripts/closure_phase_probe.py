@@ -18,6 +18,9 @@ def report(tag):
     tot = v[:4].sum()
     print("%s: %d searches; per search %.1f fixed-point steps, %.2f kick rounds, %.1f kick probes (direction x kick)" %
           (tag, nb, v[9] / nb, v[10] / nb, v[11] / nb))
+    print("  kick rounds: %.1f source cells on average; %.1f %% of the rounds have <= 2 cells, %.1f %% 3..6, %.1f %% 7..12; rounds after "
+          "the second: %.2f per search, %.0f %% of them with <= 6 cells" %
+          (v[12] / v[10], 100 * v[13] / v[10], 100 * v[14] / v[10], 100 * v[15] / v[10], v[5] / nb, 100 * v[6] / max(v[5], 1)))
     for i, nm in enumerate(names):
         print("  %-40s %8.0f cycles/search  (%.1f %%)" % (nm, v[i] / nb, 100 * v[i] / tot))
 L.trl_debug_cprof(buf, 1)

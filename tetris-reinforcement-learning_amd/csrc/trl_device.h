@@ -677,6 +677,19 @@ static __device__ __forceinline__ int movegen_closure_wave(const uint16_t *rows,
         done |= src;
         if (!__ballot(src != 0)) break;
         PROF_T(c_k0); CPROF_ADD(10, 0ull, 1ull);
+#ifdef TRL_PROFILE
+        {   // how many source cells does this round have (a round costs the same whether 1 or 100)
+            const int cells = __builtin_amdgcn_readlane(wave_incl_scan(__popcll(src), lane), 63);
+            if (lane == 0) {
+                atomicAdd(&g_cprof[12], (unsigned long long)cells);
+                if (cells <= 2) atomicAdd(&g_cprof[13], 1ull);
+                else if (cells <= 6) atomicAdd(&g_cprof[14], 1ull);
+                else if (cells <= 12) atomicAdd(&g_cprof[15], 1ull);
+                if (round >= 2) atomicAdd(&g_cprof[5], 1ull);
+                if (round >= 2 && cells <= 6) atomicAdd(&g_cprof[6], 1ull);
+            }
+        }
+#endif
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             const int nrot = (rot + d + 1) & 3;
