@@ -352,6 +352,9 @@ class SelfPlay:
             out = buf[:n * _eng.RECORD_DTYPE.itemsize].clone()
             head.zero_()
         self._side.synchronize()
+        # the clone lives in the side stream's pool and is read by the caller's stream (torch.cat, the copy in front of the
+        # RCCL gather): the allocator must not hand the block out again before that stream has used it
+        out.record_stream(torch.cuda.current_stream(self.device))
         self._acc_busy[i] = False
         return out, {k: int(h[1 + j]) for j, k in enumerate(DRAIN_HEAD_FIELDS)}
 
