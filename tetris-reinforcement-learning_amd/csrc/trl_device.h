@@ -578,6 +578,7 @@ static __device__ __forceinline__ bool resolve_mixed_wave(CsScratch &C, int lane
         }
         if (__ballot(deep)) { ok = false; break; }
         const uint64_t win = wave_max_u64(t, lane);
+        if (win == 0) { ok = false; break; }                                             // no arrival found: not this rule's case
         if (lane == L) {
             unsigned long long *w = reinterpret_cast<unsigned long long *>(&C.arr[(win & 1) ? 0 : 1][rK * 20 + xK + 2]);
             *w &= ~(1ull << yK);                                                         // the losing class leaves the cell
