@@ -877,3 +877,26 @@ def test_boards_the_tower_has_seen_are_not_evaluated_again(monkeypatch):
     (a, sa), (b, sb) = out
     assert sb["boards_reused"] == 0 and sa["boards_reused"] > 0
     assert len(a) == len(b) > 64 and a.tobytes() == b.tobytes()
+
+
+def test_board_table_in_long_searches_with_the_wide_tower(monkeypatch):
+    """the board table at C5's search length (MAX_ITER = 800: searches of 400 and 2000 simulations, forced playouts and
+    policy-target pruning) with a 64-filter net -- the tower launch that takes the live boards first -- against the same
+    job with every board sent to the tower: the same records, and well over half of the boards served from the table"""
+    torch.manual_seed(0)
+    mc = trl.AlphaSameConfig(blocks=2, filters=64)
+    net = trl.AlphaSame(mc).cuda().prepare()
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=800, training=True,
+                     use_forced_playouts_and_policy_target_pruning=True)
+    out = []
+    for table in ("1", "0"):
+        monkeypatch.setenv("TRL_BOARD_TABLE", table)
+        sp = trl.SelfPlay(cfg, net, 48, seed=11, auto_reset=True)
+        assert sp.fused_select and not sp.legal_in_tower
+        sp.tick(2600)
+        st = sp.stats()
+        assert st["overflow"] == 0 and st["records_dropped"] == 0 and st["tower_overflow"] == 0
+        out.append((_sorted_records(sp), st))
+    (a, sa), (b, sb) = out
+    assert sb["boards_reused"] == 0 and sa["boards_reused"] > 0.5 * sa["simulations"], (sa, sb)
+    assert sa["moves"] == sb["moves"] >= 48 and a.tobytes() == b.tobytes()
