@@ -585,7 +585,7 @@ def main():
     ap.add_argument("--c5-ticks", type=int, default=1200, help="timed search ticks of the C5 measurement")
     ap.add_argument("--c5-warmup", type=int, default=50)
     ap.add_argument("--no-c1", action="store_true", help="skip the C1 (single game) measurement")
-    ap.add_argument("--rank-timeout", type=float, default=300.0,
+    ap.add_argument("--rank-timeout", type=float, default=900.0,
                     help="N > 1: seconds after which ranks that are still running are ended and the run fails (exit 124)")
     args = ap.parse_args()
 
