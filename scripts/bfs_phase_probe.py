@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import tetris_rl_amd as trl
 from tetris_rl_amd import engine
-L = engine.load_library(os.path.join(os.path.dirname(os.path.abspath(__file__)), "_prof", "libtrl_prof.so"))
+L = engine.load_library(os.environ.get("TRL_ALT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_prof", "libtrl_prof.so"))
 engine._lib = L
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024         # 256: one workgroup per CU, a search alone on its SIMD (latency)
 e = trl.Engine(n, seed=20260630); e.reset(); e.rollout_random(30)

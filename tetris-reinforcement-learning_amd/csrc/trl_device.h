@@ -212,8 +212,10 @@ static __device__ __forceinline__ int placements_to_moves(const SCR &S, int type
 // hold / next (Player.create_piece must succeed, player.py:37-44).  Writes the encoded
 // placements of this piece type in ascending order to out[] and returns their number;
 // *overflow is set when a cap was hit.
+// `stop`: optional LDS word another wave sets when this walk's result is no longer wanted (block_movegen_spec); looked at
+// once per batch of queue items; the walk then returns -1
 static __device__ __forceinline__ int movegen_ordered_wave(const uint16_t *rows, int type, bool need_spawn, MgScratch &S,
-                            uint16_t *out, int out_cap, int lane, int *overflow) {
+                            uint16_t *out, int out_cap, int lane, int *overflow, const int *stop = nullptr) {
 #ifdef TRL_PROFILE
     unsigned long long prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -247,7 +249,9 @@ static __device__ __forceinline__ int movegen_ordered_wave(const uint16_t *rows,
         if (lane == 0) S.queue[0] = (uint16_t)((sx + 2) | ((sy + 2) << 4));
         wave_sync();
 
+        bool stopped = false;
         while (head < tail) {
+            if (stop && uni(*reinterpret_cast<const volatile int *>(stop))) { stopped = true; break; }
             PROF_T(q0);
             // classify up to 64 queued items at once
             int idx = head + lane;
@@ -369,8 +373,11 @@ static __device__ __forceinline__ int movegen_ordered_wave(const uint16_t *rows,
         }
         PROF_T(c0);
 
-        total = placements_to_moves(S, type, out, out_cap, lane);
-        if (total > out_cap) { *overflow = 1; total = out_cap; }
+        if (stopped) total = -1;
+        else {
+            total = placements_to_moves(S, type, out, out_cap, lane);
+            if (total > out_cap) { *overflow = 1; total = out_cap; }
+        }
         PROF_T(c1); PROF_ADD(5, c0, c1);
     }
     wave_sync();

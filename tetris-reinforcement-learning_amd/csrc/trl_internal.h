@@ -69,6 +69,66 @@ __device__ __forceinline__ uint16_t merged_move(const BlockShared &sh, int i) {
     return i < na ? sh.list[a][i] : sh.list[1 - a][i - na];
 }
 
+// The same for a workgroup of 256 threads whose waves 2 and 3 would otherwise idle (the legal-move job of the tower launch,
+// trl_net.hip): waves 0 and 1 search the two piece slots with the closure and the mixed-cell rule; beside them waves 2 and
+// 3 start the ORDERED WALK of a slot whose piece is T -- speculatively: 96 % of the T searches do not need it and call it
+// off (`stop`, looked at once per batch of queue items), but for the ones that do the walk is then well on its way instead
+// of starting when the closure gives up -- closure 8 us + walk 32 us one after the other was what a launch with 256 slots
+// lasted in four launches of five (48 us against the tower's 40).  Same lists as block_movegen.
+struct SpecShared {
+    MgScratch mg[2];
+    alignas(4) uint16_t list[2][TRL_MAX_LEGAL];
+    int cnt[2], ovf[2];
+    int stop[2];            // set by the closure wave of the slot: the walk's result is not needed
+    int need[2];            // set by the closure wave of the slot: it is
+};
+static __device__ __forceinline__ int block_movegen_spec(BlockShared &sh, SpecShared &sp, int tid) {
+    const int wave = tid >> 6, lane = tid & 63, slot = wave & 1;
+    if (tid == 0) {
+        sh.overflow = 0; sh.cnt[0] = 0; sh.cnt[1] = 0; sh.order = 0;
+        sp.stop[0] = 0; sp.stop[1] = 0; sp.need[0] = 0; sp.need[1] = 0; sp.cnt[0] = 0; sp.cnt[1] = 0; sp.ovf[0] = 0; sp.ovf[1] = 0;
+    }
+    __syncthreads();
+    const trl_game_state &g = sh.g;
+    const bool live = !is_terminal(g) && !no_move(g);
+    if (live) {
+        const trl_player_state &p = g.p[g.turn];
+        int t0, t1;
+        movegen_types(p, &t0, &t1);
+        const int type = slot == 0 ? t0 : t1;
+        if (wave < 2) {
+            if (type != P_NONE) {
+                int ovf = 0;
+                CsScratch &C = reinterpret_cast<CsScratch &>(sh.mg[slot]);
+                int n = movegen_closure_wave(p.rows, type, slot == 1, C, sh.list[slot], TRL_MAX_LEGAL, lane, &ovf);
+                if (n == -2) n = movegen_closure_finish_mixed(C, sh.list[slot], TRL_MAX_LEGAL, lane, &ovf);
+                if (lane == 0) {
+                    if (n >= 0) { sh.cnt[slot] = n; if (ovf) sh.overflow = 1; sp.stop[slot] = 1; }
+                    else sp.need[slot] = 1;
+                }
+            }
+            if (tid == 0) {
+                int b0 = t0 != P_NONE ? C_PLANE_BASE[t0] : 99, b1 = t1 != P_NONE ? C_PLANE_BASE[t1] : 99;
+                sh.order = b1 < b0 ? 1 : 0;
+            }
+        } else if (type == PT) {
+            int ovf = 0;
+            const int n = movegen_ordered_wave(p.rows, type, slot == 1, sp.mg[slot], sp.list[slot], TRL_MAX_LEGAL, lane, &ovf, &sp.stop[slot]);
+            if (lane == 0) { sp.cnt[slot] = n; sp.ovf[slot] = ovf; }
+        }
+    }
+    __syncthreads();
+    if (live && wave < 2 && sp.need[slot]) {              // the closure stopped at cells the rule does not settle: the walk's list
+        const int n = sp.cnt[slot];
+        for (int i = lane; i < n; i += 64) sh.list[slot][i] = sp.list[slot][i];
+        if (lane == 0) { sh.cnt[slot] = n; if (sp.ovf[slot]) sh.overflow = 1; }
+    }
+    __syncthreads();
+    int total = sh.cnt[0] + sh.cnt[1];
+    if (total > TRL_MAX_LEGAL) { total = TRL_MAX_LEGAL; if (tid == 0) sh.overflow = 1; }
+    return total;
+}
+
 // the same with the reference's default generator, 'brute-force' (move_generation.py:204-243; row M6): k_legal_bruteforce
 // and the search when Config.move_algorithm says so (ai.py:84, 414).  48 KB of LDS per workgroup (the cell-by-cell queue).
 struct BfBlockShared {
@@ -137,6 +197,20 @@ struct LeafLegalJob {
     unsigned long long *counters;       // [5] += 1 when a legal-move cap was hit
     int cap_states, n_slots;
 };
+
+// all 256 threads of a workgroup call it (block_movegen_spec: the ordered walk of a T search starts beside the closure)
+static __device__ __forceinline__ void leaf_legal_block_spec(const LeafLegalJob &J, BlockShared &sh, SpecShared &sp, int slot, int tid) {
+    const int phase = J.ctl[slot].phase, kind = J.ctl[slot].leaf_kind, sidx = J.ctl[slot].leaf_state;
+    if (phase != 1 || kind != 0) return;
+    load_state(sh, J.pool + (size_t)slot * J.cap_states + sidx, tid);
+    __syncthreads();
+    const int nlegal = block_movegen_spec(sh, sp, tid);
+    for (int i = tid; i < nlegal; i += 2 * BLOCK) J.leaf_moves[(size_t)slot * TRL_MAX_LEGAL + i] = merged_move(sh, i);
+    if (tid == 0) {
+        J.ctl[slot].leaf_nlegal = nlegal;
+        if (sh.overflow) { J.ctl[slot].overflow = 1; atomicAdd(&J.counters[5], 1ull); }
+    }
+}
 
 // all BLOCK (128) threads of a workgroup call it
 static __device__ __forceinline__ void leaf_legal_block(const LeafLegalJob &J, BlockShared &sh, int slot, int tid) {

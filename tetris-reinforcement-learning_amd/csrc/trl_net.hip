@@ -428,6 +428,9 @@ __device__ __forceinline__ void conv3x3s(const SBase (&sb)[7], int d1, int d10, 
 
 // LEGAL: the first job.n_slots workgroups of the launch run the search's legal-move job instead of a board
 // (leaf_legal_block, trl_internal.h: two of their four waves, the others end at once); board b is workgroup n_slots + b
+#ifndef TRL_SPEC_WALK
+#define TRL_SPEC_WALK 1      // 0: the legal-move job's waves 2, 3 end at once; a T search that needs the walk starts it after its closure
+#endif
 struct NoLegalJob {};
 template <int MINB, bool ILV, bool LEGAL = false>
 __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *__restrict__ boards, const float *__restrict__ wts,
@@ -437,9 +440,14 @@ __global__ __launch_bounds__(TRUNK_THREADS, MINB) void k_trunk16s(const float *_
     int block_id = blockIdx.x;
     if constexpr (LEGAL) {
         if (block_id < job.n_slots) {
-            if (threadIdx.x >= BLOCK) return;
             __shared__ BlockShared lsh;
+#if TRL_CLOSURE && TRL_SPEC_WALK
+            __shared__ SpecShared lsp;          // all four waves: two closures, two speculative ordered walks (T slots)
+            leaf_legal_block_spec(job, lsh, lsp, block_id, threadIdx.x);
+#else
+            if (threadIdx.x >= BLOCK) return;
             leaf_legal_block(job, lsh, block_id, threadIdx.x);
+#endif
             return;
         }
         block_id -= job.n_slots;
