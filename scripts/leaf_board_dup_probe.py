@@ -8,12 +8,15 @@ import torch
 import tetris_rl_amd as trl
 slots = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 700
+warm = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # ticks played before counting (later game phases)
 torch.manual_seed(0)
 mc = trl.AlphaSameConfig(blocks=10, filters=16)
 net = trl.AlphaSame(mc)
 cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=160, training=True)
 os.environ["TRL_LEGAL_IN_TOWER"] = "0"
 sp = trl.SelfPlay(cfg, net, slots, seed=20260630, auto_reset=True, use_graph=True)
+if warm:
+    sp.tick(warm); sp.synchronize()
 seen_search = [set() for _ in range(slots)]       # boards of the current search
 seen_slot = [set() for _ in range(slots)]         # boards of the slot's earlier searches of this game
 last_iter = np.zeros(slots, dtype=np.int64)
@@ -48,6 +51,7 @@ for t in range(ticks):
         elif key in seen_slot[s]:
             dup_prev += 1
         seen_search[s].add(key)
+print("after %d ticks of play: " % warm, end="")
 print("%d leaf evaluations: %.1f %% of the mover's boards were evaluated earlier in the same search, another %.1f %% in an "
       "earlier search of the slot" % (tot, 100.0 * dup_search / tot, 100.0 * dup_prev / tot))
 for k in sorted(by_iter):
