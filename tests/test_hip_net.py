@@ -900,3 +900,48 @@ def test_board_table_in_long_searches_with_the_wide_tower(monkeypatch):
     (a, sa), (b, sb) = out
     assert sb["boards_reused"] == 0 and sa["boards_reused"] > 0.5 * sa["simulations"], (sa, sb)
     assert sa["moves"] == sb["moves"] >= 48 and a.tobytes() == b.tobytes()
+
+
+def test_legal_job_of_the_tower_launch_on_synthetic_boards():
+    """the legal-move job inside the tower launch (closure on two waves, the speculative ordered walk of a T slot on the other
+    two: block_movegen_spec) on 4 096 synthetic boards, half of them with a T to place: the root's children after one tick
+    are the oracle's legal moves of the position, in its order"""
+    import oracle_py as op
+    from test_hip_parity import _state_for_case
+    rng = np.random.default_rng(77)
+    n = 4096
+    states = []
+    for i in range(n):
+        rows = np.zeros(40, dtype=np.uint16)
+        h = int(rng.integers(3, 21))
+        p_fill = rng.uniform(0.35, 0.85)
+        well = int(rng.integers(0, 10)) if rng.random() < 0.5 else -1
+        for r in range(40 - h, 40):
+            cells = rng.random(10) < (p_fill * (0.6 + 0.4 * (r - (40 - h)) / max(h - 1, 1)))
+            if well >= 0 and rng.random() < 0.85:
+                cells[well] = False
+            if cells.all():
+                cells[int(rng.integers(0, 10))] = False
+            rows[r] = int(sum(1 << c for c in range(10) if cells[c]))
+        piece = 6 if rng.random() < 0.5 else int(rng.integers(0, 7))
+        st = _state_for_case(rows, piece, int(rng.choice([7, 6, int(rng.integers(0, 7))])), int(rng.integers(0, 7)))
+        st[144:144 + 80] = st[0:80]                                    # the other player: any valid board
+        st[144 + 137] = int(rng.integers(0, 7))
+        states.append(st)
+    states = np.stack(states)
+    torch.manual_seed(0)
+    mc = trl.AlphaSameConfig(blocks=2, filters=16)
+    net = trl.AlphaSame(mc).cuda().prepare()
+    cfg = trl.Config(visual=False, model="pytorch", model_config=mc, MAX_ITER=16, training=False)
+    sp = trl.SelfPlay(cfg, net, n, seed=5, auto_reset=False, max_nodes=4096)
+    assert sp.fused_select and sp.legal_in_tower
+    sp.engine.set_state(states)
+    sp.tick(1)
+    sp.synchronize()
+    counts, moves, visits, q, p = sp.engine.mcts_root_children()
+    live = 0
+    for g in range(n):
+        want = op.OracleGame(state=states[g]).legal_moves()
+        assert counts[g] == len(want) and np.array_equal(moves[g, :counts[g]], want), "synthetic board %d" % g
+        live += int(len(want) > 0)
+    assert live > 0.8 * n and sp.stats()["overflow"] == 0
