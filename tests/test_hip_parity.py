@@ -336,3 +336,73 @@ def test_legal_lists_on_synthetic_boards_match_the_oracle():
         nonempty += int(len(want) > 0)
         t_searches += int(states[i][137] == 6 or states[i][138] == 6)
     assert nonempty > 0.8 * n and t_searches > 0.5 * n
+
+
+def test_moves_on_synthetic_boards_match_the_oracle():
+    """a move on each of 6 000 synthetic positions -- on every other one the move that sends / clears most, else a random one -- (stacks with holes, wells and overhangs; pending garbage on
+    both sides; combos and back-to-back runs under way; half of them with a T to place, so T-spin recognition, all-spin
+    minis, line clears, attack, cancelling and garbage entry all fire) through k_step, against the oracle's make_move"""
+    rng = np.random.default_rng(31337)
+    n = 6000
+    states = []
+    for i in range(n):
+        rows = np.zeros(40, dtype=np.uint16)
+        h = int(rng.integers(3, 20))
+        p_fill = rng.uniform(0.5, 0.93)
+        well = int(rng.integers(0, 10))
+        for r in range(40 - h, 40):
+            cells = rng.random(10) < p_fill
+            cells[well if rng.random() < 0.8 else int(rng.integers(0, 10))] = False
+            rows[r] = int(sum(1 << c for c in range(10) if cells[c]))
+        piece = 6 if rng.random() < 0.5 else int(rng.integers(0, 7))
+        st = _state_for_case(rows, piece, int(rng.choice([7, 6, int(rng.integers(0, 7))])), int(rng.integers(0, 7)))
+        st[144:144 + 80] = np.roll(st[0:80], 2 * int(rng.integers(0, 4)))   # the other player: a stack of its own
+        st[144 + 137] = int(rng.integers(0, 7))
+        for pl in (0, 144):                                              # pending garbage (columns as nibbles), stats
+            glen = int(rng.integers(0, 9)) if rng.random() < 0.5 else 0
+            g = rng.integers(0, 10, size=glen)
+            for k, col in enumerate(g):
+                st[pl + 80 + k // 2] |= np.uint8(int(col) << (4 * (k % 2)))
+            st[pl + 140] = glen
+            st[pl + 134:pl + 136] = np.array([int(rng.integers(0, 5))], dtype="<i2").view(np.uint8)     # combo under way
+        st[288:292] = np.array([i], dtype="<u4").view(np.uint8)          # RNG stream of the game
+        states.append(st)
+    states = np.stack(states)
+    e = trl.Engine(n, ruleset="s2", seed=SEED)
+    e.set_state(states)
+    canon = e.get_state()                                                # (the engine's canonical form of what was set)
+    cnt, mv = e.legal_moves()
+    # every other position plays the move that sends / clears most (tried on the oracle): random moves hardly ever clear a line
+    def stat(st, mover, off):
+        return int(st[144 * mover + off:144 * mover + off + 4].view("<i4")[0])
+    pick = np.zeros(n, dtype=np.uint16)
+    for i in range(n):
+        if not cnt[i]:
+            continue
+        if i % 2:
+            pick[i] = mv[i, int(rng.integers(0, cnt[i]))]
+            continue
+        mover, best, best_key = int(canon[i][312]), mv[i, 0], (-1, -1)
+        for m in mv[i, :cnt[i]]:
+            g = op.OracleGame(ruleset=2, seed=SEED, state=canon[i])
+            g.make_move(int(m))
+            out = g.export()
+            key = (stat(out, mover, 124) - stat(canon[i], mover, 124), stat(out, mover, 128) - stat(canon[i], mover, 128))
+            if key > best_key:
+                best, best_key = m, key
+        pick[i] = best
+    live = cnt > 0
+    e.step(pick, add_bag=True, check_legal=True)
+    got = e.get_state()
+    cleared = sent = 0
+    for i in np.nonzero(live)[0]:
+        g = op.OracleGame(ruleset=2, seed=SEED, state=canon[i])
+        g.make_move(int(pick[i]))
+        want = g.export()
+        assert np.array_equal(got[i], want), "position %d, move %d: bytes %s" % (i, pick[i], np.nonzero(got[i] != want)[0][:12])
+        mover = int(canon[i][312])
+        lc = lambda st: int(st[144 * mover + 128:144 * mover + 132].view("<i4")[0])     # stats.lines_cleared of the mover
+        ls = lambda st: int(st[144 * mover + 124:144 * mover + 128].view("<i4")[0])     # stats.lines_sent
+        cleared += int(lc(want) > lc(canon[i]))
+        sent += int(ls(want) > ls(canon[i]))
+    assert live.sum() > 0.8 * n and cleared > 500 and sent > 300, (int(live.sum()), cleared, sent)
